@@ -1,0 +1,665 @@
+/*
+ * mf_oracle.c -- CPU restatement of the reference's matrix-factorisation SGD path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the shipped product (libmf.so, the HIP
+ * kernels, the host code under question-recommendation-system_amd/) includes,
+ * links or calls this file.  It is used by tests/, by __graft_entry__.smoke()
+ * and by bench.py's cpu_baseline leg, and there only as the checker.
+ *
+ * What it restates (all citations are /root/reference/mf/mf.cpp unless noted):
+ *   read_triplet 3367-3394, collect_info 462-484, gen_random_map 1009-1017,
+ *   shuffle_problem 775-791, scale_problem 517-527, grid_problem 793-858,
+ *   init_model 952-1007, Scheduler 89-220 (one worker), SolverBase::run (SSE)
+ *   1201-1238, calc_z 1264-1273, L2_MFR::prepare_for_sg_update 1720-1728,
+ *   MFSolver::sg_update (SSE) 1462-1548, fpsg_core 2774-2943, fpsg 2945-3042,
+ *   scale_model 529-553, shrink_model 1057-1074, shuffle_model 1027-1055,
+ *   model_to_array 3415-3441, array_to_model 3444-3481, utility_train
+ *   3483-3535, utility_predict 3537-3568, mf_predict 4295-4314, calc_rmse
+ *   4316-4331, calc_reg2 608-633, mf_get_default_param 4538-4557.
+ *
+ * Third-party pieces the reference leans on, restated from their published
+ * algorithms (not present under /root/reference; the toolchain here is
+ * GCC 11.4 / glibc 2.35):
+ *   - std::minstd_rand0 (= std::default_random_engine in libstdc++):
+ *       x <- 16807 * x mod (2^31 - 1), default seed 1.
+ *   - std::generate_canonical<float,24> over minstd_rand0: one draw,
+ *       float(x - 1) / 2147483648.0f, clamped below 1.
+ *   - std::random_shuffle(first,last): for i = 1..n-1 swap(a[i], a[rand() % (i+1)]).
+ *   - glibc srand()/rand() (TYPE_3 additive feedback generator, degree 31,
+ *       separation 3, 310 warm-up draws).
+ *
+ * Parity pinning: tests/test_oracle_vs_reference.py checks this file bit for
+ * bit against the reference itself, compiled from /root/reference by
+ * oracle/Makefile into oracle/_ref/libmf_ref.so and run with one worker
+ * thread (quiet=true), and against the committed fixtures under
+ * tests/golden/ that were produced by that same build.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <xmmintrin.h>
+#include <pmmintrin.h>
+
+#include "mf_oracle.h"
+
+/* ------------------------------------------------------------------------ */
+/* libstdc++ / glibc generators, restated                                   */
+/* ------------------------------------------------------------------------ */
+
+/* std::minstd_rand0::operator() */
+static inline uint32_t minstd0_next(uint32_t *state)
+{
+    *state = (uint32_t)(((uint64_t)(*state) * 16807u) % 2147483647u);
+    return *state;
+}
+
+/* std::uniform_real_distribution<float>(0,1)(minstd_rand0&) as libstdc++
+ * builds it from generate_canonical<float, 24>. */
+static inline float canon_float(uint32_t *state)
+{
+    uint32_t x = minstd0_next(state);
+    float ret = (float)(x - 1u) / 2147483648.0f;
+    if (ret >= 1.0f)
+        ret = nextafterf(1.0f, 0.0f);
+    return ret;
+}
+
+float orc_canon_float(uint32_t *state) { return canon_float(state); }
+
+/* glibc TYPE_3 random(): r[i] = r[i-3] + r[i-31], output r[i] >> 1. */
+void orc_glibc_srand(orc_glibc_rand_t *g, unsigned seed)
+{
+    int32_t word;
+    int i;
+    if (seed == 0)
+        seed = 1;
+    g->r[0] = (int32_t)seed;
+    word = (int32_t)seed;
+    for (i = 1; i < 31; i++) {
+        long hi = word / 127773;
+        long lo = word % 127773;
+        long w = 16807 * lo - 2836 * hi;
+        if (w < 0)
+            w += 2147483647;
+        word = (int32_t)w;
+        g->r[i] = word;
+    }
+    g->f = 3;
+    g->b = 0;
+    for (i = 0; i < 310; i++)
+        (void)orc_glibc_rand(g);
+}
+
+int orc_glibc_rand(orc_glibc_rand_t *g)
+{
+    uint32_t val = (uint32_t)g->r[g->f] + (uint32_t)g->r[g->b];
+    g->r[g->f] = (int32_t)val;
+    g->f = (g->f + 1) % 31;
+    g->b = (g->b + 1) % 31;
+    return (int)(val >> 1);
+}
+
+/* gen_random_map, mf.cpp:1009-1017: srand(0); iota; std::random_shuffle. */
+void orc_gen_random_map(int size, int *map)
+{
+    orc_glibc_rand_t g;
+    int i;
+    orc_glibc_srand(&g, 0);
+    for (i = 0; i < size; i++)
+        map[i] = i;
+    for (i = 1; i < size; i++) {
+        int j = orc_glibc_rand(&g) % (i + 1);
+        if (i != j) {
+            int t = map[i];
+            map[i] = map[j];
+            map[j] = t;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Pre-processing                                                           */
+/* ------------------------------------------------------------------------ */
+
+/* read_triplet, mf.cpp:3367-3394: ids travel as floats, truncated to int. */
+void orc_read_triplet(const float *tri, int triplet_num, orc_node *R, int *m, int *n)
+{
+    int mm = 0, nn = 0;
+    long long j;
+    for (j = 0; j < triplet_num; j++) {
+        orc_node N;
+        N.u = (int)tri[3 * j];
+        N.v = (int)tri[3 * j + 1];
+        N.r = tri[3 * j + 2];
+        if (N.u + 1 > mm)
+            mm = N.u + 1;
+        if (N.v + 1 > nn)
+            nn = N.v + 1;
+        R[j] = N;
+    }
+    *m = mm;
+    *n = nn;
+}
+
+/* collect_info, mf.cpp:462-484 (sequential order; the reference's OpenMP
+ * reduction order is unspecified, the float casts absorb the difference). */
+void orc_collect_info(const orc_node *R, long long nnz, float *avg, float *std_dev)
+{
+    double ex = 0, ex2 = 0;
+    long long i;
+    for (i = 0; i < nnz; i++) {
+        ex += (double)R[i].r;
+        ex2 += (double)R[i].r * R[i].r;
+    }
+    ex /= (double)nnz;
+    ex2 /= (double)nnz;
+    *avg = (float)ex;
+    *std_dev = (float)sqrt(ex2 - ex * ex);
+}
+
+static int cmp_by_p(const void *a, const void *b)
+{
+    const orc_node *x = (const orc_node *)a, *y = (const orc_node *)b;
+    if (x->u != y->u)
+        return x->u < y->u ? -1 : 1;
+    if (x->v != y->v)
+        return x->v < y->v ? -1 : 1;
+    return 0;
+}
+
+static int cmp_by_q(const void *a, const void *b)
+{
+    const orc_node *x = (const orc_node *)a, *y = (const orc_node *)b;
+    if (x->v != y->v)
+        return x->v < y->v ? -1 : 1;
+    if (x->u != y->u)
+        return x->u < y->u ? -1 : 1;
+    return 0;
+}
+
+/* grid_problem, mf.cpp:793-858.  R is permuted in place into nr_bins^2
+ * contiguous blocks, each sorted by (u,v) when m > n, else by (v,u).  With
+ * unique (u,v) pairs the result does not depend on the sort algorithm. */
+void orc_grid_problem(orc_node *R, long long nnz, int m, int n, int nr_bins,
+                      long long *ptrs /* nr_bins^2+1 */, int *omega_p, int *omega_q)
+{
+    int nb = nr_bins * nr_bins;
+    int seg_p = (int)ceil((double)m / nr_bins);
+    int seg_q = (int)ceil((double)n / nr_bins);
+    long long *counts = (long long *)calloc((size_t)nb, sizeof(long long));
+    long long *pivots = (long long *)malloc((size_t)nb * sizeof(long long));
+    long long i;
+    int b;
+
+    for (i = 0; i < nnz; i++) {
+        int blk = (R[i].u / seg_p) * nr_bins + R[i].v / seg_q;
+        counts[blk]++;
+        omega_p[R[i].u]++;
+        omega_q[R[i].v]++;
+    }
+    ptrs[0] = 0;
+    for (b = 0; b < nb; b++)
+        ptrs[b + 1] = ptrs[b] + counts[b];
+    for (b = 0; b < nb; b++)
+        pivots[b] = ptrs[b];
+    for (b = 0; b < nb; b++) {
+        long long pivot = pivots[b];
+        while (pivot != ptrs[b + 1]) {
+            int cur = (R[pivot].u / seg_p) * nr_bins + R[pivot].v / seg_q;
+            if (cur == b) {
+                pivot++;
+                continue;
+            }
+            {
+                long long next = pivots[cur];
+                orc_node t = R[pivot];
+                R[pivot] = R[next];
+                R[next] = t;
+                pivots[cur]++;
+            }
+        }
+    }
+    for (b = 0; b < nb; b++)
+        qsort(R + ptrs[b], (size_t)(ptrs[b + 1] - ptrs[b]), sizeof(orc_node),
+              m > n ? cmp_by_p : cmp_by_q);
+    free(counts);
+    free(pivots);
+}
+
+/* init_model, mf.cpp:952-1007.  Returns the padded factor count k_a. */
+int orc_k_aligned(int k) { return (int)ceil((double)k / 8) * 8; }
+
+void orc_init_model(int m, int n, int k, const int *omega_p, const int *omega_q,
+                    float *P, float *Q)
+{
+    int ka = orc_k_aligned(k);
+    float scale = (float)sqrt(1.0 / k);
+    uint32_t gen = 1; /* default_random_engine default seed */
+    int side;
+    for (side = 0; side < 2; side++) {
+        float *base = side == 0 ? P : Q;
+        long long size = side == 0 ? m : n;
+        const int *cnt = side == 0 ? omega_p : omega_q;
+        long long i;
+        int d;
+        memset(base, 0, sizeof(float) * (size_t)size * (size_t)ka);
+        for (i = 0; i < size; i++) {
+            float *ptr = base + i * ka;
+            if (cnt[i] > 0)
+                for (d = 0; d < k; d++)
+                    ptr[d] = (float)(canon_float(&gen) * scale);
+            else
+                for (d = 0; d < k; d++)
+                    ptr[d] = NAN;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* The per-rating update                                                    */
+/* ------------------------------------------------------------------------ */
+
+static inline float rsqrt_as(int mode, float x)
+{
+    if (mode == ORC_RSQRT_SSE)
+        return _mm_cvtss_f32(_mm_rsqrt_ss(_mm_set_ss(x)));
+    return 1.0f / sqrtf(x);
+}
+
+/* calc_z (SSE), mf.cpp:1264-1273: four lane partials over d = j (mod 4),
+ * then two horizontal adds. */
+static inline float dot_sse_order(const float *p, const float *q, int ka)
+{
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int d;
+    for (d = 0; d < ka; d += 4) {
+        a0 = a0 + p[d] * q[d];
+        a1 = a1 + p[d + 1] * q[d + 1];
+        a2 = a2 + p[d + 2] * q[d + 2];
+        a3 = a3 + p[d + 3] * q[d + 3];
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+
+/* MFSolver::sg_update (SSE), mf.cpp:1462-1548, with lambda1 = 0, no NMF. */
+static inline void sg_update_range(float *p, float *q, float *pG, float *qG,
+                                   int d_begin, int d_end, float e,
+                                   float lambda_p, float lambda_q, float eta,
+                                   float rk, int rsqrt_mode)
+{
+    float eta_p = eta * rsqrt_as(rsqrt_mode, *pG);
+    float eta_q = eta * rsqrt_as(rsqrt_mode, *qG);
+    float gp[4] = {0, 0, 0, 0}, gq[4] = {0, 0, 0, 0};
+    int d, j;
+    for (d = d_begin; d < d_end; d += 4) {
+        for (j = 0; j < 4; j++) {
+            float pv = p[d + j], qv = q[d + j];
+            float pg = lambda_p * pv - e * qv;
+            float qg = lambda_q * qv - e * pv;
+            gp[j] = gp[j] + pg * pg;
+            gq[j] = gq[j] + qg * qg;
+            p[d + j] = pv - eta_p * pg;
+            q[d + j] = qv - eta_q * qg;
+        }
+    }
+    *pG = *pG + ((gp[0] + gp[1]) + (gp[2] + gp[3])) * rk;
+    *qG = *qG + ((gq[0] + gq[1]) + (gq[2] + gq[3])) * rk;
+}
+
+/* One rating: SolverBase::run body, mf.cpp:1222-1234.  Returns e. */
+float orc_sgd_one(float *p, float *q, float *pG, float *qG, float r, int ka,
+                  float lambda_p, float lambda_q, float eta, int slow_only,
+                  int rsqrt_mode, int rk_mode)
+{
+    float z = dot_sse_order(p, q, ka);
+    float e = r - z;
+    float rk_slow = (float)1.0 / 8;
+    /* quirk Q1: the SSE build passes rk_slow to both halves (mf.cpp:1233-1234);
+     * the AVX/scalar builds pass 1/(k_a-8) (mf.cpp:1314-1315, 1383) */
+    float rk_second = (rk_mode == ORC_RK_AS_BUILT || ka == 8) ? rk_slow : (float)1.0 / (ka - 8);
+    sg_update_range(p, q, pG, qG, 0, 8, e, lambda_p, lambda_q, eta, rk_slow, rsqrt_mode);
+    if (slow_only)
+        return e;
+    sg_update_range(p, q, pG + 1, qG + 1, 8, ka, e, lambda_p, lambda_q, eta,
+                    rk_second, rsqrt_mode);
+    return e;
+}
+
+/* ------------------------------------------------------------------------ */
+/* One-worker block scheduler (mf.cpp:89-220) as a (priority, id) min-heap   */
+/* ------------------------------------------------------------------------ */
+
+typedef struct { float pr; int id; } hent;
+
+static inline int hless(hent a, hent b)
+{
+    if (a.pr != b.pr)
+        return a.pr < b.pr;
+    return a.id < b.id;
+}
+
+static void hpush(hent *h, int *n, hent e)
+{
+    int i = (*n)++;
+    h[i] = e;
+    while (i > 0) {
+        int par = (i - 1) / 2;
+        if (!hless(h[i], h[par]))
+            break;
+        {
+            hent t = h[i];
+            h[i] = h[par];
+            h[par] = t;
+        }
+        i = par;
+    }
+}
+
+static hent hpop(hent *h, int *n)
+{
+    hent top = h[0];
+    int i = 0;
+    h[0] = h[--(*n)];
+    for (;;) {
+        int l = 2 * i + 1, r = l + 1, s = i;
+        if (l < *n && hless(h[l], h[s]))
+            s = l;
+        if (r < *n && hless(h[r], h[s]))
+            s = r;
+        if (s == i)
+            break;
+        {
+            hent t = h[i];
+            h[i] = h[s];
+            h[s] = t;
+        }
+        i = s;
+    }
+    return top;
+}
+
+/* calc_reg2, mf.cpp:608-633 with Utility::inner_product (SSE) 555-566. */
+static double reg2_side(const float *base, long long size, int ka, const int *omega)
+{
+    double reg = 0;
+    long long i;
+    for (i = 0; i < size; i++) {
+        if (omega[i] <= 0)
+            continue;
+        reg += omega[i] * dot_sse_order(base + i * ka, base + i * ka, ka);
+    }
+    return reg;
+}
+
+orc_param orc_default_param(void)
+{
+    /* mf_get_default_param, mf.cpp:4538-4557 (nr_threads is fixed to one here) */
+    orc_param p;
+    p.k = 8;
+    p.nr_bins = 20;
+    p.nr_iters = 20;
+    p.lambda_p2 = 0.1f;
+    p.lambda_q2 = 0.1f;
+    p.eta = 0.1f;
+    p.rsqrt_mode = ORC_RSQRT_SSE;
+    p.rk_mode = ORC_RK_AS_BUILT;
+    return p;
+}
+
+/* fpsg + fpsg_core + mf_train_with_validation for P_L2_MFR, one worker. */
+int orc_train(const orc_node *R_in, long long nnz, int m, int n, const orc_param *prm,
+              orc_model *out, double *tr_rmse, double *obj)
+{
+    int nb, ka, k = prm->k, iter, b;
+    orc_node *R;
+    int *p_map, *q_map, *omega_p, *omega_q, *counts;
+    long long *ptrs;
+    float avg, std_dev, scale, inv_scale, lambda_p, lambda_q, *P, *Q, *PG, *QG;
+    double *block_loss;
+    hent *heap;
+    int hn = 0;
+    uint32_t sched_gen = 1;
+    long long i;
+    unsigned old_ftz;
+
+    if (k < 1 || prm->nr_bins < 1 || prm->nr_iters < 1 || prm->lambda_p2 < 0 ||
+        prm->lambda_q2 < 0 || prm->eta <= 0)
+        return -1; /* check_parameter, mf.cpp:3115-3184 */
+    if (nnz == 0 || m <= 0 || n <= 0)
+        return -2;
+
+    nb = prm->nr_bins * prm->nr_bins;
+    ka = orc_k_aligned(k);
+
+    R = (orc_node *)malloc((size_t)nnz * sizeof(orc_node));
+    memcpy(R, R_in, (size_t)nnz * sizeof(orc_node));
+
+    /* Scheduler constructor (mf.cpp:105-110) runs first and draws the initial
+     * priorities from its own default-seeded engine. */
+    heap = (hent *)malloc((size_t)nb * sizeof(hent));
+    counts = (int *)calloc((size_t)nb, sizeof(int));
+    for (b = 0; b < nb; b++) {
+        hent e;
+        e.pr = canon_float(&sched_gen);
+        e.id = b;
+        hpush(heap, &hn, e);
+    }
+
+    orc_collect_info(R, nnz, &avg, &std_dev);
+    scale = std_dev > (float)1e-4 ? std_dev : (float)1e-4; /* mf.cpp:2999 */
+
+    p_map = (int *)malloc((size_t)m * sizeof(int));
+    q_map = (int *)malloc((size_t)n * sizeof(int));
+    orc_gen_random_map(m, p_map);
+    orc_gen_random_map(n, q_map);
+    omega_p = (int *)calloc((size_t)m, sizeof(int));
+    omega_q = (int *)calloc((size_t)n, sizeof(int));
+
+    inv_scale = (float)1.0 / scale; /* mf.cpp:3010 */
+    for (i = 0; i < nnz; i++) {
+        R[i].u = p_map[R[i].u];
+        R[i].v = q_map[R[i].v];
+    }
+    if (inv_scale != 1.0f)
+        for (i = 0; i < nnz; i++)
+            R[i].r *= inv_scale;
+
+    ptrs = (long long *)malloc((size_t)(nb + 1) * sizeof(long long));
+    orc_grid_problem(R, nnz, m, n, prm->nr_bins, ptrs, omega_p, omega_q);
+
+    P = (float *)aligned_alloc(32, sizeof(float) * (size_t)m * (size_t)ka);
+    Q = (float *)aligned_alloc(32, sizeof(float) * (size_t)n * (size_t)ka);
+    orc_init_model(m, n, k, omega_p, omega_q, P, Q);
+
+    lambda_p = prm->lambda_p2 / scale; /* mf.cpp:2805-2806 */
+    lambda_q = prm->lambda_q2 / scale;
+
+    PG = (float *)malloc(sizeof(float) * 2 * (size_t)m);
+    QG = (float *)malloc(sizeof(float) * 2 * (size_t)n);
+    for (i = 0; i < 2LL * m; i++)
+        PG[i] = 1;
+    for (i = 0; i < 2LL * n; i++)
+        QG[i] = 1;
+    block_loss = (double *)calloc((size_t)nb, sizeof(double));
+
+    old_ftz = _MM_GET_FLUSH_ZERO_MODE();
+    _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_ON); /* mf.cpp:2789-2790 */
+
+    for (iter = 0; iter < prm->nr_iters; iter++) {
+        int slow_only = iter == 0; /* mf.cpp:2834, 2910-2911 */
+        int job;
+        for (job = 0; job < nb; job++) {
+            hent e = hpop(heap, &hn); /* get_job: nothing else is busy */
+            double loss = 0;
+            long long t;
+            counts[e.id]++;
+            for (t = ptrs[e.id]; t < ptrs[e.id + 1]; t++) {
+                orc_node *N = &R[t];
+                float err = orc_sgd_one(P + (long long)N->u * ka, Q + (long long)N->v * ka,
+                                        PG + 2LL * N->u, QG + 2LL * N->v, N->r, ka,
+                                        lambda_p, lambda_q, prm->eta, slow_only,
+                                        prm->rsqrt_mode, prm->rk_mode);
+                loss += (double)(err * err);
+            }
+            block_loss[e.id] = loss;
+            e.pr = (float)counts[e.id] + canon_float(&sched_gen); /* put_job */
+            hpush(heap, &hn, e);
+        }
+        if (tr_rmse || obj) { /* progress row, mf.cpp:2852-2908 */
+            double tr_loss = 0, reg;
+            for (b = 0; b < nb; b++)
+                tr_loss += block_loss[b];
+            reg = lambda_p * reg2_side(P, m, ka, omega_p) +
+                  lambda_q * reg2_side(Q, n, ka, omega_q);
+            if (tr_rmse)
+                tr_rmse[iter] = sqrt(tr_loss / nnz * scale * scale);
+            if (obj)
+                obj[iter] = reg * scale * scale + tr_loss * (double)(float)(scale * scale);
+        }
+    }
+    _MM_SET_FLUSH_ZERO_MODE(old_ftz);
+
+    /* scale_model, shrink_model, shuffle_model -> model in original ids */
+    out->fun = 0;
+    out->m = m;
+    out->n = n;
+    out->k = k;
+    out->b = avg / scale;
+    if (scale != 1.0f)
+        out->b *= scale;
+    out->P = (float *)malloc(sizeof(float) * (size_t)m * (size_t)k);
+    out->Q = (float *)malloc(sizeof(float) * (size_t)n * (size_t)k);
+    {
+        float fs = scale != 1.0f ? sqrtf(scale) : 1.0f;
+        int d;
+        for (i = 0; i < m; i++)
+            for (d = 0; d < k; d++) {
+                float x = P[(long long)p_map[i] * ka + d];
+                out->P[i * k + d] = scale != 1.0f ? x * fs : x;
+            }
+        for (i = 0; i < n; i++)
+            for (d = 0; d < k; d++) {
+                float x = Q[(long long)q_map[i] * ka + d];
+                out->Q[i * k + d] = scale != 1.0f ? x * fs : x;
+            }
+    }
+
+    free(R); free(heap); free(counts); free(p_map); free(q_map);
+    free(omega_p); free(omega_q); free(ptrs); free(P); free(Q);
+    free(PG); free(QG); free(block_loss);
+    return 0;
+}
+
+void orc_free_model(orc_model *mdl)
+{
+    free(mdl->P);
+    free(mdl->Q);
+    mdl->P = mdl->Q = NULL;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Prediction, RMSE, the float-array facade                                 */
+/* ------------------------------------------------------------------------ */
+
+/* mf_predict, mf.cpp:4295-4314 (std::inner_product order: sequential) */
+float orc_predict(const orc_model *mdl, int u, int v)
+{
+    const float *p, *q;
+    float z = 0.0f;
+    int d;
+    if (u < 0 || u >= mdl->m || v < 0 || v >= mdl->n)
+        return mdl->b;
+    p = mdl->P + (long long)u * mdl->k;
+    q = mdl->Q + (long long)v * mdl->k;
+    for (d = 0; d < mdl->k; d++)
+        z = z + p[d] * q[d];
+    if (isnan(z))
+        z = mdl->b;
+    return z;
+}
+
+/* calc_rmse, mf.cpp:4316-4331 */
+double orc_rmse(const orc_node *R, long long nnz, const orc_model *mdl)
+{
+    double loss = 0;
+    long long i;
+    if (nnz == 0)
+        return 0;
+    for (i = 0; i < nnz; i++) {
+        float e = R[i].r - orc_predict(mdl, R[i].u, R[i].v);
+        loss += e * e;
+    }
+    return sqrt(loss / nnz);
+}
+
+/* model_to_array, mf.cpp:3415-3441 */
+float *orc_model_to_array(const orc_model *mdl, int *lens)
+{
+    long long pn = (long long)mdl->m * mdl->k, qn = (long long)mdl->n * mdl->k;
+    float *a = (float *)malloc(sizeof(float) * (size_t)(pn + qn + 5));
+    a[0] = (float)mdl->fun;
+    a[1] = (float)mdl->m;
+    a[2] = (float)mdl->n;
+    a[3] = (float)mdl->k;
+    a[4] = mdl->b;
+    memcpy(a + 5, mdl->P, sizeof(float) * (size_t)pn);
+    memcpy(a + 5 + pn, mdl->Q, sizeof(float) * (size_t)qn);
+    *lens = (int)(pn + qn + 5);
+    return a;
+}
+
+/* utility_train, mf.cpp:3483-3535, driven the way SURVEY.md 8c prescribes:
+ * one worker, quiet, utility_train's parameter overrides. */
+float *orc_utility_train(const float *train, int triplets, double p_l2, double q_l2,
+                         int k, int iters, double eta, int *lens)
+{
+    orc_node *R = (orc_node *)malloc(sizeof(orc_node) * (size_t)(triplets > 0 ? triplets : 1));
+    orc_param prm = orc_default_param();
+    orc_model mdl;
+    float *arr;
+    int m, n;
+    orc_read_triplet(train, triplets, R, &m, &n);
+    prm.lambda_p2 = (float)p_l2;
+    prm.lambda_q2 = (float)q_l2;
+    prm.k = k;
+    prm.nr_iters = iters;
+    prm.eta = (float)eta;
+    if (orc_train(R, triplets, m, n, &prm, &mdl, NULL, NULL) != 0) {
+        free(R);
+        *lens = 0;
+        return NULL;
+    }
+    arr = orc_model_to_array(&mdl, lens);
+    orc_free_model(&mdl);
+    free(R);
+    return arr;
+}
+
+/* utility_predict, mf.cpp:3537-3568 (array_to_model 3444-3481: a length
+ * mismatch yields no model; the reference then dereferences null, the
+ * restatement returns NULL). */
+float *orc_utility_predict(const float *test, int pairs, const float *model_arr, int model_len)
+{
+    orc_model mdl;
+    long long pn, qn;
+    float *out;
+    int i;
+    mdl.fun = (int)model_arr[0];
+    mdl.m = (int)model_arr[1];
+    mdl.n = (int)model_arr[2];
+    mdl.k = (int)model_arr[3];
+    mdl.b = model_arr[4];
+    pn = (long long)mdl.m * mdl.k;
+    qn = (long long)mdl.n * mdl.k;
+    if ((long long)model_len != pn + qn + 5)
+        return NULL;
+    mdl.P = (float *)(model_arr + 5);
+    mdl.Q = (float *)(model_arr + 5 + pn);
+    out = (float *)malloc(sizeof(float) * (size_t)(pairs > 0 ? pairs : 1));
+    for (i = 0; i < pairs; i++)
+        out[i] = orc_predict(&mdl, (int)test[2 * i], (int)test[2 * i + 1]);
+    return out;
+}
+
+void orc_free(void *p) { free(p); }
