@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- ratings/s per SGD epoch of the MI355X matrix-factorisation trainer.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one full-k SGD epoch (the per-rating loop of reference mf/mf.cpp:1201-1238 over
+every rating) on BASELINE.json configs[1]: synthetic 100k x 50k, 10 M ratings, k = 32, generated
+in HBM.  With N GPUs each rank trains its own 100k-user shard of an (N*100k) x 50k problem
+(weak scaling); the item factors Q and their Adagrad slots are replicated and averaged over
+RCCL after every epoch, inside the timed region.  Epoch 0 (slow_only, 8 of k factors) and the
+one-off pre-processing are outside the timed region, as in SURVEY.md 8(d).
+
+Prints ONE JSON line (rank 0): metric/value/unit per the driver contract, plus
+  roofline     -- algorithmic HBM bytes per launch / mean launch time (HIP events) vs 8 TB/s
+  cpu_baseline -- the reference CPU trainer (oracle/_ref) or, if absent, the oracle port,
+                  timed on this host by the iteration-delta method (rank 0, N = 1 only)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+WORKLOAD = dict(m=100000, n=50000, nnz=10000000, k=32, lambda_p=0.1, lambda_q=0.1, eta=0.1, seed=1)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(pkg, w, budget_s=25.0):
+    """Reference CPU epoch rate on this host (iteration-delta)."""
+    orc = ge.import_oracle()
+    cores = os.cpu_count() or 1
+    m, n, k = w["m"], w["n"], w["k"]
+    if orc.have_ref():
+        R = pkg.synth_host(w["seed"], 0, w["nnz"], m, n)
+        threads, bins = 12, 20  # the facade's hard-wired values (reference mf/mf.cpp:4544-4545)
+        n1, n2 = 2, 12
+        best = None
+        t_start = time.time()
+        for _ in range(3):
+            t1, _r = orc.ref_time_train(R, m, n, k, n1, threads, bins)
+            t2, rm = orc.ref_time_train(R, m, n, k, n2, threads, bins)
+            per_epoch = (t2 - t1) / (n2 - n1)
+            if per_epoch > 0 and (best is None or per_epoch < best[0]):
+                best = (per_epoch, rm)
+            if time.time() - t_start > budget_s:
+                break
+        out = {"value": len(R) / best[0], "unit": "ratings/s", "cores": min(threads, cores),
+               "kind": "reference", "threads": threads, "bins": threads and bins, "host_cores": cores,
+               "rmse_after_%d_epochs" % n2: best[1],
+               "sample": "full workload (10M ratings), mf_train quiet, T(%d it)-T(%d it), min of <=3" % (n2, n1)}
+        # all-core leg (nr_bins = max(20, 2*threads+1), reference mf/mf.cpp:3142,3177-3181)
+        if time.time() - t_start < budget_s and cores > threads:
+            th = min(cores, 64)
+            bn = max(20, 2 * th + 1)
+            t1, _r = orc.ref_time_train(R, m, n, k, n1, th, bn)
+            t2, _r = orc.ref_time_train(R, m, n, k, n2, th, bn)
+            if t2 > t1:
+                out["value_allcores"] = len(R) * (n2 - n1) / (t2 - t1)
+                out["allcores_threads"] = th
+        return out
+    # port: one-thread restatement on a 2M-rating sample of the same stream
+    ns = 2000000
+    R = pkg.synth_host(w["seed"], 0, ns, m, n)
+    t0 = time.time(); orc.train(R, m, n, k=k, iters=2); t1 = time.time() - t0
+    t0 = time.time(); orc.train(R, m, n, k=k, iters=6); t2 = time.time() - t0
+    return {"value": ns * 4 / max(t2 - t1, 1e-9), "unit": "ratings/s", "cores": 1, "kind": "port",
+            "host_cores": cores, "sample": "first 2M ratings of the workload, oracle C port, T(6 it)-T(2 it)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nnz", type=int, default=WORKLOAD["nnz"], help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no HIP device visible)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = ge.import_package()
+    w = dict(WORKLOAD)
+    w["nnz"] = args.nnz
+    m, n, nnz, k = w["m"], w["n"], w["nnz"], w["k"]
+
+    # ratings of this rank's user shard, generated straight into HBM
+    R_dev = torch.empty(nnz * 3, dtype=torch.int32, device=dev)
+    pkg.synth_device(w["seed"], 0, nnz, m, n, R_dev.data_ptr(), None, shard=rank)
+    torch.cuda.synchronize()
+
+    opts = pkg.default_options(k=k, lambda_p2=w["lambda_p"], lambda_q2=w["lambda_q"], eta=w["eta"],
+                               device=local_rank)
+    t = pkg.Trainer(None, m, n, opts=opts, device_ptr=R_dev.data_ptr(), nnz=nnz)
+    del R_dev
+    info = t.info
+    ka = info.k_aligned
+    # factors live in torch tensors so RCCL can reduce them in place
+    P = torch.empty(m * ka, dtype=torch.float32, device=dev)
+    Q = torch.empty(n * ka, dtype=torch.float32, device=dev)
+    PG = torch.empty(m * 2, dtype=torch.float32, device=dev)
+    QG = torch.empty(n * 2, dtype=torch.float32, device=dev)
+    t.bind_model(P.data_ptr(), Q.data_ptr(), PG.data_ptr(), QG.data_ptr())
+    t.init_model()  # same seed stream on every rank: Q starts identical everywhere
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def epoch(slow=False):
+        t.epoch(slow_only=slow, stream=stream)
+        if world > 1:  # replicated item factors: average over xGMI
+            dist.all_reduce(Q, op=dist.ReduceOp.AVG)
+            dist.all_reduce(QG, op=dist.ReduceOp.AVG)
+
+    epoch(slow=True)  # the reference's epoch 0 (8 of k factors): not part of the metric
+    for _ in range(args.warmup):
+        epoch()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        epoch()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    launches, kern_ms = t.timing_read()
+    t.timing_enable(False)
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    rmse = t.rmse()
+    epochs_total = 1 + args.warmup + args.steps
+
+    if rank == 0:
+        value = world * nnz * args.steps / elapsed
+        bytes_per_launch = info.bytes_per_rating * nnz / info.stripes
+        avg_launch_s = kern_ms / 1e3 / max(launches, 1)
+        achieved = bytes_per_launch / avg_launch_s / 1e9
+        out = {
+            "metric": "ratings/sec per SGD epoch", "value": value, "unit": "ratings/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: synthetic %dx%d, %d ratings, k=%d per GPU "
+                                   "(user-sharded; Q averaged over RCCL each epoch when N>1)" % (m, n, nnz, k),
+                       "m_per_gpu": m, "n": n, "nnz_per_gpu": nnz, "k": k, "lambda": w["lambda_p"],
+                       "eta": w["eta"], "stripes": info.stripes, "wgs_per_launch": None},
+            "final_rmse": rmse, "epochs_trained": epochs_total,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "sgd_round<%d>" % info.lanes_per_rating,
+                         "bytes_per_rating": info.bytes_per_rating,
+                         "ratings_per_launch": nnz / info.stripes,
+                         "avg_launch_us": avg_launch_s * 1e6, "launches_timed": launches},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(pkg, w)
+            except Exception as e:  # the baseline is a report, never a reason to lose the line
+                out["cpu_baseline"] = {"value": None, "unit": "ratings/s", "cores": 0, "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    t.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

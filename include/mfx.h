@@ -1,0 +1,168 @@
+/* mfx.h -- thin HIP C-ABI of the MI355X-native SGD matrix-factorisation trainer.
+ *
+ * Plain C: pointers, sizes, an opaque handle.  No torch / C++ types.  Every entry
+ * returns 0 on success and a negative mfx_status on failure (message via
+ * mfx_last_error()); nothing throws or aborts across this boundary.
+ *
+ * Where an entry replaces something in the reference it says so
+ * (paths relative to /root/reference).  The reference has no device boundary at
+ * all: these entries are what mf/mf.cpp's fpsg()/fpsg_core() pipeline
+ * (mf.cpp:2774-3042) looks like once the per-rating loop (mf.cpp:1201-1238,
+ * 1462-1548, 1720-1728) lives in HBM.  include/mf.h keeps the reference's own
+ * C++ surface on top of them; INTEGRATION.md shows the bindings.
+ */
+#ifndef MFX_H
+#define MFX_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFX_ABI_VERSION 1
+
+enum mfx_status {
+    MFX_OK = 0,
+    MFX_E_ARG = -1,      /* bad argument (check_parameter, mf.cpp:3115-3184)          */
+    MFX_E_EMPTY = -2,    /* empty training set (mf.cpp:2792-2796)                     */
+    MFX_E_HIP = -3,      /* HIP runtime error / no gfx950 device                      */
+    MFX_E_NOMEM = -4,
+    MFX_E_UNSUPPORTED = -5, /* k too large for the kernel family, lambda1 != 0, nmf   */
+    MFX_E_STATE = -6
+};
+
+/* mf_node, mf/mf.h:36-41: 12 bytes, no padding. */
+typedef struct mfx_node { int u; int v; float r; } mfx_node;
+
+typedef struct mfx_trainer mfx_trainer;
+
+typedef struct mfx_options {
+    int k;             /* latent factors (mf_parameter.k, mf/mf.h:54)                  */
+    float lambda_p2;   /* mf/mf.h:59                                                   */
+    float lambda_q2;   /* mf/mf.h:61                                                   */
+    float eta;         /* mf/mf.h:62                                                   */
+    int device;        /* HIP ordinal; -1 = current device                             */
+    int stripes;       /* stripe count per side = launches per epoch; 0 = one per XCD  */
+    int wg_per_cu;     /* resident 256-thread workgroups per CU; 0 = auto              */
+    int task_steps;    /* ratings per lane-group per task; 0 = auto                    */
+    int reserved0;     /* unused (was an experiment knob); keep 0                      */
+    int rk_mode;       /* 0: 1/8 for both accumulator slots (SSE build as shipped,
+                          mf.cpp:1233-1234); 1: 1/(k_a-8) for slot 1 (mf.cpp:1314-1315) */
+    int owner_side;    /* 0 auto (side with fewer rows), 1 users (P), 2 items (Q)      */
+    int identity_maps; /* 1: skip the id permutation (tests)                           */
+    int reserved[4];
+} mfx_options;
+
+typedef struct mfx_info {
+    int m, n, k, k_aligned;
+    long long nnz;
+    float avg, std_dev, scale;       /* collect_info, mf.cpp:462-484; scale mf.cpp:2999  */
+    float lambda_p_scaled, lambda_q_scaled; /* mf.cpp:2805-2806                         */
+    int stripes, lanes_per_rating, ratings_per_wave;
+    int owner_is_q;
+    long long n_entries;             /* nnz + padding slots                              */
+    long long n_tasks;
+    long long n_hot_rows;
+    int cu_count, xcd_count, wg_per_cu;
+    void *dP, *dQ, *dPG, *dQG;       /* device pointers (internal ids, k_aligned stride) */
+    double bytes_per_rating;         /* algorithmic: 16*k_aligned + 44    */
+} mfx_info;
+
+int mfx_abi_version(void);
+const char *mfx_last_error(void);
+int mfx_device_count(void);
+void mfx_default_options(mfx_options *opt);
+
+/* Pre-processing + upload.  Replaces fpsg() up to init_model (mf.cpp:2972-3016):
+ * collect_info, gen_random_map, shuffle_problem, scale_problem, and a GPU stripe/task
+ * layout in place of grid_problem.  R is borrowed host memory (copy_data semantics). */
+int mfx_trainer_create(const mfx_node *R_host, long long nnz, int m, int n,
+                       const mfx_options *opt, mfx_trainer **out);
+/* Same, ratings already resident in HBM (device pointer). */
+int mfx_trainer_create_device(const void *R_dev, long long nnz, int m, int n,
+                              const mfx_options *opt, mfx_trainer **out);
+void mfx_trainer_destroy(mfx_trainer *t);
+
+/* Use caller-owned device buffers for the factors (k_aligned stride, internal ids):
+ * P m*k_a, Q n*k_a, PG 2m, QG 2n floats.  Lets a host framework hand the same memory
+ * to RCCL.  Must precede mfx_trainer_init_model. */
+int mfx_trainer_bind_model(mfx_trainer *t, void *dP, void *dQ, void *dPG, void *dQG);
+
+/* init_model (mf.cpp:952-1007) + the accumulator fill (mf.cpp:2835), bit-identical to
+ * the reference's stream.  omega_q_override (host, n ints, may be NULL) replaces the local
+ * item counts when several ranks share Q. */
+int mfx_trainer_init_model(mfx_trainer *t, const int *omega_q_override);
+
+/* One SGD epoch = `stripes` kernel launches on `stream` (hipStream_t as void*, NULL =
+ * the trainer's own stream).  slow_only = 1 reproduces epoch 0 (mf.cpp:2834, 1230-1231).
+ * Asynchronous. */
+int mfx_trainer_epoch(mfx_trainer *t, int slow_only, void *stream);
+int mfx_trainer_sync(mfx_trainer *t);
+
+/* Online sum of squared errors of the last finished epoch in scaled units
+ * (the Scheduler::get_loss figure, mf.cpp:237-241).  Synchronises. */
+int mfx_trainer_last_loss(mfx_trainer *t, double *sum_sq);
+/* calc_reg2 (mf.cpp:608-633) on the device, scaled units. */
+int mfx_trainer_reg2(mfx_trainer *t, double *reg);
+/* Training-set RMSE of the current factors in original rating units
+ * (calc_rmse formula, mf.cpp:4316-4331).  Synchronises. */
+int mfx_trainer_rmse(mfx_trainer *t, double *rmse);
+
+int mfx_trainer_info(mfx_trainer *t, mfx_info *info);
+/* host copies of the id permutations (gen_random_map, mf.cpp:1009-1017): m and n ints */
+int mfx_trainer_maps(mfx_trainer *t, int *p_map, int *q_map);
+/* raw factors in internal layout, for tests and checkpoints */
+int mfx_trainer_get_model(mfx_trainer *t, float *P, float *Q, float *PG, float *QG);
+int mfx_trainer_set_model(mfx_trainer *t, const float *P, const float *Q, const float *PG,
+                          const float *QG);
+
+/* HIP-event timing of the epoch launches (events on the launch stream).  After
+ * mfx_trainer_sync: number of launches timed since enable and their summed duration. */
+int mfx_trainer_timing_enable(mfx_trainer *t, int on);
+int mfx_trainer_timing_read(mfx_trainer *t, long long *launches, double *total_ms);
+
+/* scale_model + shrink_model + shuffle_model + model_to_array
+ * (mf.cpp:529-553, 1057-1074, 1027-1055, 3415-3441): writes
+ * [fun,m,n,k,b,P(m*k),Q(n*k)] to host memory; len must equal 5+(m+n)*k. */
+int mfx_trainer_export(mfx_trainer *t, float *model_arr, long long len);
+
+/* utility_predict's loop (mf.cpp:3537-3568, mf_predict 4295-4314) batched on the
+ * device: pairs = (u,v) as floats, out = float[npairs].  Host buffers. */
+int mfx_predict_array(const float *model_arr, long long model_len, const float *pairs,
+                      long long npairs, float *out);
+/* calc_rmse (mf.cpp:4316-4331) of a facade array on host ratings, on the device. */
+int mfx_rmse_array(const float *model_arr, long long model_len, const mfx_node *R,
+                   long long nnz, double *rmse);
+
+/* Host-only view of the pre-processing result (no device needed): lets the CPU test
+ * suite check the id maps, row counts, statistics, initial factors and the stripe/task
+ * layout against the oracle.  Pointers stay valid until mfx_hostplan_destroy. */
+typedef struct mfx_hostplan mfx_hostplan;
+typedef struct mfx_plan_view {
+    int m, n, k, k_aligned, stripes, lanes_per_rating, ratings_per_wave, owner_is_q;
+    long long nnz, n_entries, n_tasks, n_padding, n_hot_rows;
+    float avg, std_dev, scale, inv_scale;
+    const int *p_map, *q_map, *omega_p, *omega_q;
+    const void *entries;            /* {uint32 own|boundary<<31, int32 gat(-1 = pad), float r} */
+    const void *tasks;              /* {uint64 entry_off, uint32 nsteps, uint32 pad}            */
+    const long long *slot_task_ptr; /* stripes*stripes+1, ordered (round, slot)                */
+} mfx_plan_view;
+int mfx_hostplan_build(const mfx_node *R_host, long long nnz, int m, int n,
+                       const mfx_options *opt, mfx_hostplan **out);
+int mfx_hostplan_view(const mfx_hostplan *h, mfx_plan_view *view);
+/* init_model (mf.cpp:952-1007): P m*k_aligned, Q n*k_aligned floats, internal ids */
+int mfx_hostplan_init_factors(const mfx_hostplan *h, float *P, float *Q);
+void mfx_hostplan_destroy(mfx_hostplan *h);
+
+/* Deterministic synthetic ratings: integer-only generator, identical on
+ * host and device.  Writes ratings [first, first+count) of shard `shard` of problem `seed`:
+ * a shard is one GPU's user range (m users of its own, the n items shared by all shards);
+ * shard 0 alone is the single-GPU problem. */
+int mfx_synth_host(unsigned long long seed, unsigned long long shard, long long first,
+                   long long count, int m, int n, mfx_node *out);
+int mfx_synth_device(unsigned long long seed, unsigned long long shard, long long first,
+                     long long count, int m, int n, void *out_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFX_H */

@@ -267,6 +267,10 @@ static inline float rsqrt_as(int mode, float x)
     return 1.0f / sqrtf(x);
 }
 
+/* What this host's rsqrtss returns: the approximation differs between CPU vendors
+ * (SURVEY.md 3.4, quirk Q3), so golden vectors made on one vendor are bit-exact only there. */
+float orc_rsqrt_probe(float x) { return rsqrt_as(ORC_RSQRT_SSE, x); }
+
 /* calc_z (SSE), mf.cpp:1264-1273: four lane partials over d = j (mod 4),
  * then two horizontal adds. */
 static inline float dot_sse_order(const float *p, const float *q, int ka)

@@ -42,6 +42,7 @@ int orc_k_aligned(int k);
 void orc_init_model(int m, int n, int k, const int *omega_p, const int *omega_q,
                     float *P, float *Q);
 
+float orc_rsqrt_probe(float x);
 float orc_sgd_one(float *p, float *q, float *pG, float *qG, float r, int ka,
                   float lambda_p, float lambda_q, float eta, int slow_only,
                   int rsqrt_mode, int rk_mode);

@@ -1,0 +1,241 @@
+"""ctypes view of the CPU checker: oracle/liboracle.so (the C restatement) and, when it has been
+built in the development container, oracle/_ref (the reference itself).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Never imported by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+NODE = np.dtype([("u", "<i4"), ("v", "<i4"), ("r", "<f4")])
+
+RSQRT_SSE, RSQRT_EXACT = 0, 1
+RK_AS_BUILT, RK_FAST = 0, 1
+
+
+class Param(C.Structure):
+    _fields_ = [("k", C.c_int), ("nr_bins", C.c_int), ("nr_iters", C.c_int),
+                ("lambda_p2", C.c_float), ("lambda_q2", C.c_float), ("eta", C.c_float),
+                ("rsqrt_mode", C.c_int), ("rk_mode", C.c_int)]
+
+
+class Model(C.Structure):
+    _fields_ = [("fun", C.c_int), ("m", C.c_int), ("n", C.c_int), ("k", C.c_int),
+                ("b", C.c_float), ("P", C.POINTER(C.c_float)), ("Q", C.POINTER(C.c_float))]
+
+
+class GlibcRand(C.Structure):
+    _fields_ = [("r", C.c_int32 * 31), ("f", C.c_int), ("b", C.c_int)]
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "all"], cwd=_HERE)
+        L = C.CDLL(path)
+        vp, ll, i32, f32 = C.c_void_p, C.c_longlong, C.c_int, C.c_float
+        L.orc_train.argtypes = [vp, ll, i32, i32, C.POINTER(Param), C.POINTER(Model), vp, vp]
+        L.orc_rmse.restype = C.c_double
+        L.orc_rmse.argtypes = [vp, ll, C.POINTER(Model)]
+        L.orc_predict.restype = f32
+        L.orc_predict.argtypes = [C.POINTER(Model), i32, i32]
+        L.orc_free_model.argtypes = [C.POINTER(Model)]
+        L.orc_gen_random_map.argtypes = [i32, vp]
+        L.orc_collect_info.argtypes = [vp, ll, C.POINTER(f32), C.POINTER(f32)]
+        L.orc_grid_problem.argtypes = [vp, ll, i32, i32, i32, vp, vp, vp]
+        L.orc_init_model.argtypes = [i32, i32, i32, vp, vp, vp, vp]
+        L.orc_k_aligned.argtypes = [i32]
+        L.orc_read_triplet.argtypes = [vp, i32, vp, C.POINTER(i32), C.POINTER(i32)]
+        L.orc_sgd_one.restype = f32
+        L.orc_sgd_one.argtypes = [vp, vp, vp, vp, f32, i32, f32, f32, f32, i32, i32, i32]
+        L.orc_rsqrt_probe.restype = f32
+        L.orc_rsqrt_probe.argtypes = [f32]
+        L.orc_utility_train.restype = C.POINTER(f32)
+        L.orc_utility_train.argtypes = [vp, i32, C.c_double, C.c_double, i32, i32, C.c_double, C.POINTER(i32)]
+        L.orc_utility_predict.restype = C.POINTER(f32)
+        L.orc_utility_predict.argtypes = [vp, i32, vp, i32]
+        L.orc_free.argtypes = [vp]
+        L.orc_glibc_srand.argtypes = [C.POINTER(GlibcRand), C.c_uint]
+        L.orc_glibc_rand.argtypes = [C.POINTER(GlibcRand)]
+        L.orc_canon_float.restype = f32
+        L.orc_canon_float.argtypes = [C.POINTER(C.c_uint32)]
+        _lib = L
+    return _lib
+
+
+def have_ref():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libref_harness.so"))
+
+
+def ref():
+    """The reference itself (oracle/_ref, built by `make -C oracle ref` from /root/reference)."""
+    global _ref
+    if _ref is None:
+        L = C.CDLL(os.path.join(_HERE, "_ref", "libref_harness.so"))
+        vp, ll, i32, f32 = C.c_void_p, C.c_longlong, C.c_int, C.c_float
+        L.ref_train_array.restype = C.POINTER(f32)
+        L.ref_train_array.argtypes = [vp, ll, i32, i32, i32, i32, i32, i32, f32, f32, f32, C.POINTER(ll)]
+        L.ref_rmse_array.restype = C.c_double
+        L.ref_rmse_array.argtypes = [vp, ll, i32, i32, vp]
+        L.ref_utility_predict.restype = C.POINTER(f32)
+        L.ref_utility_predict.argtypes = [vp, i32, vp, i32]
+        L.ref_time_train.restype = C.c_double
+        L.ref_time_train.argtypes = [vp, ll, i32, i32, i32, i32, i32, i32, f32, f32, f32, C.POINTER(C.c_double)]
+        L.ref_free.argtypes = [vp]
+        _ref = L
+    return _ref
+
+
+def rsqrt_signature():
+    """Bits of this host's rsqrtss on a few inputs (vendor-specific approximation, quirk Q3)."""
+    xs = [1.5, 2.0, 3.0, 5.0, 7.0, 11.0, 123.456, 0.3]
+    return np.array([lib().orc_rsqrt_probe(x) for x in xs], dtype=np.float32).view(np.uint32)
+
+
+def k_aligned(k):
+    return lib().orc_k_aligned(k)
+
+
+def train(R, m, n, k=8, iters=20, bins=20, lambda_p=0.1, lambda_q=0.1, eta=0.1,
+          rsqrt_mode=RSQRT_SSE, rk_mode=RK_AS_BUILT, progress=False):
+    """One-worker restatement of mf_train.  Returns the facade array [fun,m,n,k,b,P,Q]
+    (and the per-iteration (tr_rmse, obj) table when progress=True)."""
+    R = np.ascontiguousarray(R, dtype=NODE)
+    prm = Param(k, bins, iters, lambda_p, lambda_q, eta, rsqrt_mode, rk_mode)
+    mdl = Model()
+    tr = np.zeros(iters)
+    ob = np.zeros(iters)
+    rc = lib().orc_train(R.ctypes.data, len(R), m, n, C.byref(prm), C.byref(mdl),
+                         tr.ctypes.data if progress else None, ob.ctypes.data if progress else None)
+    if rc != 0:
+        raise RuntimeError("orc_train failed: %d" % rc)
+    P = np.ctypeslib.as_array(mdl.P, (m * k,)).copy()
+    Q = np.ctypeslib.as_array(mdl.Q, (n * k,)).copy()
+    arr = np.concatenate([np.array([mdl.fun, mdl.m, mdl.n, mdl.k, mdl.b], dtype=np.float32), P, Q])
+    lib().orc_free_model(C.byref(mdl))
+    return (arr, tr, ob) if progress else arr
+
+
+def _model_of(arr):
+    arr = np.ascontiguousarray(arr, dtype=np.float32)
+    m, n, k = int(arr[1]), int(arr[2]), int(arr[3])
+    mdl = Model(int(arr[0]), m, n, k, float(arr[4]),
+                C.cast(arr.ctypes.data + 20, C.POINTER(C.c_float)),
+                C.cast(arr.ctypes.data + 20 + 4 * m * k, C.POINTER(C.c_float)))
+    return mdl, arr
+
+
+def rmse(R, arr):
+    R = np.ascontiguousarray(R, dtype=NODE)
+    mdl, keep = _model_of(arr)
+    return lib().orc_rmse(R.ctypes.data, len(R), C.byref(mdl))
+
+
+def predict(arr, pairs):
+    mdl, keep = _model_of(arr)
+    pairs = np.asarray(pairs, dtype=np.float32).reshape(-1, 2)
+    return np.array([lib().orc_predict(C.byref(mdl), int(u), int(v)) for u, v in pairs], dtype=np.float32)
+
+
+def utility_train(train, p_l2=0.1, q_l2=0.1, k=8, iters=20, eta=0.1):
+    t = np.ascontiguousarray(train, dtype=np.float32).ravel()
+    lens = C.c_int()
+    p = lib().orc_utility_train(t.ctypes.data, len(t) // 3, p_l2, q_l2, k, iters, eta, C.byref(lens))
+    if not p:
+        return None
+    out = np.ctypeslib.as_array(p, (lens.value,)).copy()
+    lib().orc_free(p)
+    return out
+
+
+def utility_predict(pairs, model):
+    t = np.ascontiguousarray(pairs, dtype=np.float32).ravel()
+    mdl = np.ascontiguousarray(model, dtype=np.float32)
+    p = lib().orc_utility_predict(t.ctypes.data, len(t) // 2, mdl.ctypes.data, len(mdl))
+    if not p:
+        return None
+    out = np.ctypeslib.as_array(p, (max(1, len(t) // 2),)).copy()[: len(t) // 2]
+    lib().orc_free(p)
+    return out
+
+
+def gen_random_map(size):
+    out = np.empty(size, dtype=np.int32)
+    lib().orc_gen_random_map(size, out.ctypes.data)
+    return out
+
+
+def collect_info(R):
+    R = np.ascontiguousarray(R, dtype=NODE)
+    a, s = C.c_float(), C.c_float()
+    lib().orc_collect_info(R.ctypes.data, len(R), C.byref(a), C.byref(s))
+    return a.value, s.value
+
+
+def grid_problem(R, m, n, bins):
+    """grid_problem on internal-id ratings: returns (permuted copy, block ptrs, omega_p, omega_q)."""
+    R = np.ascontiguousarray(R, dtype=NODE).copy()
+    ptrs = np.zeros(bins * bins + 1, dtype=np.int64)
+    op = np.zeros(m, dtype=np.int32)
+    oq = np.zeros(n, dtype=np.int32)
+    lib().orc_grid_problem(R.ctypes.data, len(R), m, n, bins, ptrs.ctypes.data, op.ctypes.data, oq.ctypes.data)
+    return R, ptrs, op, oq
+
+
+def init_model(m, n, k, omega_p, omega_q):
+    ka = k_aligned(k)
+    P = np.empty((m, ka), dtype=np.float32)
+    Q = np.empty((n, ka), dtype=np.float32)
+    op = np.ascontiguousarray(omega_p, dtype=np.int32)
+    oq = np.ascontiguousarray(omega_q, dtype=np.int32)
+    lib().orc_init_model(m, n, k, op.ctypes.data, oq.ctypes.data, P.ctypes.data, Q.ctypes.data)
+    return P, Q
+
+
+def sgd_apply(P, Q, PG, QG, R, ka, lambda_p, lambda_q, eta, slow_only, rsqrt_mode=RSQRT_EXACT,
+              rk_mode=RK_AS_BUILT):
+    """Apply orc_sgd_one to every rating of R in order (internal ids, scaled ratings), in place.
+    Returns the sum of squared errors in double (the online loss)."""
+    loss = 0.0
+    f = lib().orc_sgd_one
+    for u, v, r in R:
+        e = f(P[u].ctypes.data, Q[v].ctypes.data, PG[u].ctypes.data, QG[v].ctypes.data, float(r), ka,
+              lambda_p, lambda_q, eta, 1 if slow_only else 0, rsqrt_mode, rk_mode)
+        loss += float(np.float32(e) * np.float32(e))
+    return loss
+
+
+# ---- the reference itself (development container only) --------------------------------------
+
+def ref_train(R, m, n, k=8, iters=20, threads=1, bins=20, lambda_p=0.1, lambda_q=0.1, eta=0.1):
+    R = np.ascontiguousarray(R, dtype=NODE)
+    lens = C.c_longlong()
+    p = ref().ref_train_array(R.ctypes.data, len(R), m, n, k, threads, bins, iters, lambda_p, lambda_q, eta, C.byref(lens))
+    if not p:
+        return None
+    out = np.ctypeslib.as_array(p, (lens.value,)).copy()
+    ref().ref_free(p)
+    return out
+
+
+def ref_rmse(R, arr, m, n):
+    R = np.ascontiguousarray(R, dtype=NODE)
+    arr = np.ascontiguousarray(arr, dtype=np.float32)
+    return ref().ref_rmse_array(R.ctypes.data, len(R), m, n, arr.ctypes.data)
+
+
+def ref_time_train(R, m, n, k, iters, threads, bins, lambda_p=0.1, lambda_q=0.1, eta=0.1):
+    R = np.ascontiguousarray(R, dtype=NODE)
+    rm = C.c_double()
+    secs = ref().ref_time_train(R.ctypes.data, len(R), m, n, k, threads, bins, iters, lambda_p, lambda_q, eta, C.byref(rm))
+    return secs, rm.value

@@ -1,0 +1,360 @@
+"""ctypes binding of the MI355X-native libmf.so (C-ABI in include/mfx.h, mf:: facade in include/mf.h).
+
+Host-side mirror of the reference interface for this path: `utility_train` / `utility_predict`
+take and return the same float arrays as reference mf/mf.cpp:3483-3568, `Trainer` exposes the
+epoch-level device API used by bench.py and the parity tests.  This module only marshals
+pointers; every computation happens inside the shared library (HIP kernels).  There is no
+Python or CPU fallback: if the library or a GPU is missing the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmf.so")
+WARP_PATH = os.path.join(_HERE, "lib", "libmfwarp.so")
+
+NODE = np.dtype([("u", "<i4"), ("v", "<i4"), ("r", "<f4")])  # mf_node, reference mf/mf.h:36-41
+ENTRY = np.dtype([("own", "<u4"), ("gat", "<i4"), ("r", "<f4")])
+TASK = np.dtype([("off", "<u8"), ("nsteps", "<u4"), ("pad", "<u4")])
+
+# Itanium names of the five symbols an unchanged libphp_mf.so imports
+MANGLED = {
+    "utility_train": "_ZN2mf13utility_trainEPfiddiidRi",
+    "utility_predict": "_ZN2mf15utility_predictEPfiS0_i",
+    "mf_my_train": "_ZN2mf11mf_my_trainEPKcS1_",
+    "cos_similarity": "_ZN2mf14cos_similarityEiPfi",
+    "DINA": "_ZN2mf4DINAEPfiS0_ii",
+}
+
+
+class MfxError(RuntimeError):
+    pass
+
+
+class Options(C.Structure):
+    _fields_ = [("k", C.c_int), ("lambda_p2", C.c_float), ("lambda_q2", C.c_float),
+                ("eta", C.c_float), ("device", C.c_int), ("stripes", C.c_int),
+                ("wg_per_cu", C.c_int), ("task_steps", C.c_int), ("reserved0", C.c_int),
+                ("rk_mode", C.c_int), ("owner_side", C.c_int), ("identity_maps", C.c_int),
+                ("reserved", C.c_int * 4)]
+
+
+class Info(C.Structure):
+    _fields_ = [("m", C.c_int), ("n", C.c_int), ("k", C.c_int), ("k_aligned", C.c_int),
+                ("nnz", C.c_longlong), ("avg", C.c_float), ("std_dev", C.c_float),
+                ("scale", C.c_float), ("lambda_p_scaled", C.c_float),
+                ("lambda_q_scaled", C.c_float), ("stripes", C.c_int),
+                ("lanes_per_rating", C.c_int), ("ratings_per_wave", C.c_int),
+                ("owner_is_q", C.c_int), ("n_entries", C.c_longlong), ("n_tasks", C.c_longlong),
+                ("n_hot_rows", C.c_longlong), ("cu_count", C.c_int), ("xcd_count", C.c_int),
+                ("wg_per_cu", C.c_int), ("dP", C.c_void_p), ("dQ", C.c_void_p),
+                ("dPG", C.c_void_p), ("dQG", C.c_void_p), ("bytes_per_rating", C.c_double)]
+
+
+class PlanView(C.Structure):
+    _fields_ = [("m", C.c_int), ("n", C.c_int), ("k", C.c_int), ("k_aligned", C.c_int),
+                ("stripes", C.c_int), ("lanes_per_rating", C.c_int),
+                ("ratings_per_wave", C.c_int), ("owner_is_q", C.c_int),
+                ("nnz", C.c_longlong), ("n_entries", C.c_longlong), ("n_tasks", C.c_longlong),
+                ("n_padding", C.c_longlong), ("n_hot_rows", C.c_longlong),
+                ("avg", C.c_float), ("std_dev", C.c_float), ("scale", C.c_float),
+                ("inv_scale", C.c_float), ("p_map", C.c_void_p), ("q_map", C.c_void_p),
+                ("omega_p", C.c_void_p), ("omega_q", C.c_void_p), ("entries", C.c_void_p),
+                ("tasks", C.c_void_p), ("slot_task_ptr", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libmf.so once; raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MfxError("%s is missing: build it with `make -C %s` (hipcc, gfx950)" % (LIB_PATH, _HERE))
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L.mfx_last_error.restype = C.c_char_p
+    vp, ll, i32 = C.c_void_p, C.c_longlong, C.c_int
+    L.mfx_trainer_create.argtypes = [vp, ll, i32, i32, C.POINTER(Options), C.POINTER(vp)]
+    L.mfx_trainer_create_device.argtypes = [vp, ll, i32, i32, C.POINTER(Options), C.POINTER(vp)]
+    L.mfx_trainer_destroy.argtypes = [vp]
+    L.mfx_trainer_destroy.restype = None
+    L.mfx_trainer_bind_model.argtypes = [vp, vp, vp, vp, vp]
+    L.mfx_trainer_init_model.argtypes = [vp, vp]
+    L.mfx_trainer_epoch.argtypes = [vp, i32, vp]
+    L.mfx_trainer_sync.argtypes = [vp]
+    L.mfx_trainer_last_loss.argtypes = [vp, C.POINTER(C.c_double)]
+    L.mfx_trainer_reg2.argtypes = [vp, C.POINTER(C.c_double)]
+    L.mfx_trainer_rmse.argtypes = [vp, C.POINTER(C.c_double)]
+    L.mfx_trainer_info.argtypes = [vp, C.POINTER(Info)]
+    L.mfx_trainer_maps.argtypes = [vp, vp, vp]
+    L.mfx_trainer_get_model.argtypes = [vp, vp, vp, vp, vp]
+    L.mfx_trainer_set_model.argtypes = [vp, vp, vp, vp, vp]
+    L.mfx_trainer_timing_enable.argtypes = [vp, i32]
+    L.mfx_trainer_timing_read.argtypes = [vp, C.POINTER(ll), C.POINTER(C.c_double)]
+    L.mfx_trainer_export.argtypes = [vp, vp, ll]
+    L.mfx_predict_array.argtypes = [vp, ll, vp, ll, vp]
+    L.mfx_rmse_array.argtypes = [vp, ll, vp, ll, C.POINTER(C.c_double)]
+    L.mfx_hostplan_build.argtypes = [vp, ll, i32, i32, C.POINTER(Options), C.POINTER(vp)]
+    L.mfx_hostplan_view.argtypes = [vp, C.POINTER(PlanView)]
+    L.mfx_hostplan_init_factors.argtypes = [vp, vp, vp]
+    L.mfx_hostplan_destroy.argtypes = [vp]
+    L.mfx_hostplan_destroy.restype = None
+    L.mfx_synth_host.argtypes = [C.c_ulonglong, C.c_ulonglong, ll, ll, i32, i32, vp]
+    L.mfx_synth_device.argtypes = [C.c_ulonglong, C.c_ulonglong, ll, ll, i32, i32, vp, vp]
+    L.mfx_default_options.argtypes = [C.POINTER(Options)]
+    L.mfx_default_options.restype = None
+    # mf:: facade (C++ mangled names; the int& of utility_train is a pointer at the ABI)
+    f = getattr(L, MANGLED["utility_train"])
+    f.restype = C.POINTER(C.c_float)
+    f.argtypes = [vp, i32, C.c_double, C.c_double, i32, i32, C.c_double, C.POINTER(i32)]
+    f = getattr(L, MANGLED["utility_predict"])
+    f.restype = C.POINTER(C.c_float)
+    f.argtypes = [vp, i32, vp, i32]
+    f = getattr(L, MANGLED["mf_my_train"])
+    f.restype = i32
+    f.argtypes = [C.c_char_p, C.c_char_p]
+    f = getattr(L, MANGLED["cos_similarity"])
+    f.restype = C.POINTER(C.c_float)
+    f.argtypes = [i32, vp, i32]
+    f = getattr(L, MANGLED["DINA"])
+    f.restype = C.POINTER(i32)
+    f.argtypes = [vp, i32, vp, i32, i32]
+    _lib = L
+    return L
+
+
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+def _check(rc):
+    if rc != 0:
+        raise MfxError("mfx error %d: %s" % (rc, lib().mfx_last_error().decode()))
+
+
+def default_options(**kw):
+    o = Options()
+    lib().mfx_default_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def device_count():
+    return lib().mfx_device_count()
+
+
+def as_nodes(u, v, r):
+    R = np.empty(len(u), dtype=NODE)
+    R["u"], R["v"], R["r"] = u, v, r
+    return R
+
+
+def synth_host(seed, first, count, m, n, shard=0):
+    """Synthetic ratings [first, first+count) of shard `shard` (host build of the generator)."""
+    R = np.empty(count, dtype=NODE)
+    _check(lib().mfx_synth_host(seed, shard, first, count, m, n, R.ctypes.data))
+    return R
+
+
+def synth_device(seed, first, count, m, n, dev_ptr, stream=None, shard=0):
+    """Same stream written straight into HBM (dev_ptr = device address of count*12 bytes)."""
+    _check(lib().mfx_synth_device(seed, shard, first, count, m, n, dev_ptr, stream))
+
+
+# ---- float-array facade (reference mf/mf.cpp:3483-3568) -----------------------------------
+
+def utility_train(train, p_l2=0.1, q_l2=0.1, k=8, iters=20, eta=0.1):
+    """mf::utility_train: float (u,v,r) triplets -> model array [fun,m,n,k,b,P,Q] or None."""
+    t = np.ascontiguousarray(train, dtype=np.float32).ravel()
+    lens = C.c_int(0)
+    p = getattr(lib(), MANGLED["utility_train"])(t.ctypes.data, len(t) // 3, p_l2, q_l2, k, iters,
+                                                   eta, C.byref(lens))
+    if not p:
+        return None
+    out = np.ctypeslib.as_array(p, (lens.value,)).copy()
+    _libc.free(p)
+    return out
+
+
+def utility_predict(pairs, model):
+    """mf::utility_predict: float (u,v) pairs + model array -> predictions or None."""
+    t = np.ascontiguousarray(pairs, dtype=np.float32).ravel()
+    mdl = np.ascontiguousarray(model, dtype=np.float32)
+    p = getattr(lib(), MANGLED["utility_predict"])(t.ctypes.data, len(t) // 2, mdl.ctypes.data, len(mdl))
+    if not p:
+        return None
+    out = np.ctypeslib.as_array(p, (max(len(t) // 2, 1),)).copy()[: len(t) // 2]
+    _libc.free(p)
+    return out
+
+
+def predict_array(model, pairs):
+    mdl = np.ascontiguousarray(model, dtype=np.float32)
+    t = np.ascontiguousarray(pairs, dtype=np.float32).ravel()
+    out = np.empty(len(t) // 2, dtype=np.float32)
+    _check(lib().mfx_predict_array(mdl.ctypes.data, len(mdl), t.ctypes.data, len(t) // 2, out.ctypes.data))
+    return out
+
+
+def rmse_array(model, R):
+    mdl = np.ascontiguousarray(model, dtype=np.float32)
+    R = np.ascontiguousarray(R, dtype=NODE)
+    out = C.c_double()
+    _check(lib().mfx_rmse_array(mdl.ctypes.data, len(mdl), R.ctypes.data, len(R), C.byref(out)))
+    return out.value
+
+
+# ---- epoch-level device API ------------------------------------------------------------------
+
+class Trainer:
+    """Handle on one training problem resident in HBM (mfx_trainer_*)."""
+
+    def __init__(self, R, m, n, opts=None, device_ptr=None, nnz=None, **kw):
+        self.opts = opts if opts is not None else default_options(**kw)
+        self._h = C.c_void_p()
+        if device_ptr is not None:
+            _check(lib().mfx_trainer_create_device(device_ptr, nnz, m, n, C.byref(self.opts), C.byref(self._h)))
+        else:
+            R = np.ascontiguousarray(R, dtype=NODE)
+            _check(lib().mfx_trainer_create(R.ctypes.data, len(R), m, n, C.byref(self.opts), C.byref(self._h)))
+        self.info = self._info()
+
+    def _info(self):
+        i = Info()
+        _check(lib().mfx_trainer_info(self._h, C.byref(i)))
+        return i
+
+    def close(self):
+        if self._h:
+            lib().mfx_trainer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bind_model(self, dP, dQ, dPG, dQG):
+        _check(lib().mfx_trainer_bind_model(self._h, dP, dQ, dPG, dQG))
+
+    def init_model(self, omega_q=None):
+        ptr = None
+        if omega_q is not None:
+            omega_q = np.ascontiguousarray(omega_q, dtype=np.int32)
+            ptr = omega_q.ctypes.data
+        _check(lib().mfx_trainer_init_model(self._h, ptr))
+        self.info = self._info()
+
+    def epoch(self, slow_only=False, stream=None):
+        _check(lib().mfx_trainer_epoch(self._h, 1 if slow_only else 0, stream))
+
+    def sync(self):
+        _check(lib().mfx_trainer_sync(self._h))
+
+    def last_loss(self):
+        v = C.c_double()
+        _check(lib().mfx_trainer_last_loss(self._h, C.byref(v)))
+        return v.value
+
+    def reg2(self):
+        v = C.c_double()
+        _check(lib().mfx_trainer_reg2(self._h, C.byref(v)))
+        return v.value
+
+    def rmse(self):
+        v = C.c_double()
+        _check(lib().mfx_trainer_rmse(self._h, C.byref(v)))
+        return v.value
+
+    def maps(self):
+        p = np.empty(self.info.m, dtype=np.int32)
+        q = np.empty(self.info.n, dtype=np.int32)
+        _check(lib().mfx_trainer_maps(self._h, p.ctypes.data, q.ctypes.data))
+        return p, q
+
+    def get_model(self):
+        i = self.info
+        P = np.empty((i.m, i.k_aligned), dtype=np.float32)
+        Q = np.empty((i.n, i.k_aligned), dtype=np.float32)
+        PG = np.empty((i.m, 2), dtype=np.float32)
+        QG = np.empty((i.n, 2), dtype=np.float32)
+        _check(lib().mfx_trainer_get_model(self._h, P.ctypes.data, Q.ctypes.data, PG.ctypes.data, QG.ctypes.data))
+        return P, Q, PG, QG
+
+    def set_model(self, P, Q, PG, QG):
+        arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (P, Q, PG, QG)]
+        _check(lib().mfx_trainer_set_model(self._h, *[a.ctypes.data for a in arrs]))
+        self.info = self._info()
+
+    def timing_enable(self, on=True):
+        _check(lib().mfx_trainer_timing_enable(self._h, 1 if on else 0))
+
+    def timing_read(self):
+        n = C.c_longlong()
+        ms = C.c_double()
+        _check(lib().mfx_trainer_timing_read(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def export(self):
+        i = self.info
+        ln = 5 + (i.m + i.n) * i.k
+        out = np.empty(ln, dtype=np.float32)
+        _check(lib().mfx_trainer_export(self._h, out.ctypes.data, ln))
+        return out
+
+    def train(self, iters):
+        """fpsg_core's epoch loop (reference mf/mf.cpp:2848-2914): epoch 0 is slow_only."""
+        for it in range(iters):
+            self.epoch(slow_only=(it == 0))
+        self.sync()
+
+
+class HostPlan:
+    """Host-only pre-processing result (mfx_hostplan_*): needs no GPU."""
+
+    def __init__(self, R, m, n, opts=None, **kw):
+        self.opts = opts if opts is not None else default_options(**kw)
+        R = np.ascontiguousarray(R, dtype=NODE)
+        self._h = C.c_void_p()
+        _check(lib().mfx_hostplan_build(R.ctypes.data, len(R), m, n, C.byref(self.opts), C.byref(self._h)))
+        v = PlanView()
+        _check(lib().mfx_hostplan_view(self._h, C.byref(v)))
+        self.view = v
+
+        def arr(ptr, count, dtype):
+            if count == 0:
+                return np.empty(0, dtype=dtype)
+            buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype).copy()
+
+        self.p_map = arr(v.p_map, v.m, np.int32)
+        self.q_map = arr(v.q_map, v.n, np.int32)
+        self.omega_p = arr(v.omega_p, v.m, np.int32)
+        self.omega_q = arr(v.omega_q, v.n, np.int32)
+        self.entries = arr(v.entries, v.n_entries, ENTRY)
+        self.tasks = arr(v.tasks, v.n_tasks, TASK)
+        self.slot_task_ptr = arr(v.slot_task_ptr, v.stripes * v.stripes + 1, np.int64)
+
+    def init_factors(self):
+        v = self.view
+        P = np.empty((v.m, v.k_aligned), dtype=np.float32)
+        Q = np.empty((v.n, v.k_aligned), dtype=np.float32)
+        _check(lib().mfx_hostplan_init_factors(self._h, P.ctypes.data, Q.ctypes.data))
+        return P, Q
+
+    def close(self):
+        if self._h:
+            lib().mfx_hostplan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

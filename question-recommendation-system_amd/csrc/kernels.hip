@@ -1,0 +1,485 @@
+// kernels.hip -- gfx950 kernels of the SGD matrix-factorisation path.
+//
+// sgd_round<LANES> is the hot loop: it replaces the reference's per-rating worker loop
+// SolverBase::run + calc_z + L2_MFR::prepare_for_sg_update + MFSolver::sg_update
+// (reference mf/mf.cpp:1201-1238, 1264-1273, 1720-1728, 1462-1548) and the block
+// Scheduler (mf.cpp:49-312).  Design (DESIGN.md has the long form):
+//
+//  * A rating is processed by a group of LANES lanes, 4 consecutive factors per lane
+//    (one 16-byte access per lane, LANES*16 B = one coalesced row segment); a 64-wide
+//    wavefront runs 64/LANES ratings per step.  The k-dim dot and the gradient-norm sums
+//    are DPP butterflies inside the group -- no LDS, no MFMA (nothing here is a dense
+//    contraction).
+//  * "Owner computes": ratings arrive grouped by the row of one side (the owner side).
+//    The owner row and its two Adagrad slots stay in registers across the whole run and
+//    are written back once; only the other ("gathered") side's row is read and written
+//    per rating.
+//  * The conflict-free idea of the reference scheduler (no two live blocks share a row or
+//    column stripe, mf.cpp:133-141) is kept at XCD granularity: one launch = one round of
+//    NS stripe-disjoint blocks; a block is worked by the waves of ONE XCD only, so all of
+//    its rows live in that XCD's L2 and no cross-XCD coherence is needed inside a launch
+//    (the per-XCD L2s are not coherent with each other).  A wave reads HW_REG_XCC_ID and
+//    serves the blocks of its own XCD (rank, rank+X, ...): which workgroup lands where
+//    changes speed, never results.  Inside a block the XCD's waves run lock-free (Hogwild)
+//    on the gathered side; factor loads bypass the per-CU L1 so they see the XCD's L2.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+
+namespace mfx {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// ---- cross-lane helpers -------------------------------------------------------------
+
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// Sum over the LANES-lane group this lane belongs to; every lane gets the total.
+// quad_perm swaps for 1 and 2, row_half_mirror / row_mirror for 4 and 8 (valid because
+// the halves are already uniform at that point), ds_bpermute beyond a 16-lane row.
+template <int LANES>
+__device__ __forceinline__ float group_sum(float x)
+{
+    if (LANES >= 2) x += dpp<0xB1>(x);  // quad_perm [1,0,3,2]
+    if (LANES >= 4) x += dpp<0x4E>(x);  // quad_perm [2,3,0,1]
+    if (LANES >= 8) x += dpp<0x141>(x); // row_half_mirror
+    if (LANES >= 16) x += dpp<0x140>(x); // row_mirror
+    if (LANES >= 32) x += __shfl_xor(x, 16);
+    if (LANES >= 64) x += __shfl_xor(x, 32);
+    return x;
+}
+
+__device__ __forceinline__ int xcc_id()
+{
+    int x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+    return x;
+}
+
+__device__ __forceinline__ int aload(const int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// factor loads: served by the XCD's L2, never by a stale per-CU L1 line
+__device__ __forceinline__ f4 ld_row(const float *p) { return __builtin_nontemporal_load((const f4 *)p); }
+__device__ __forceinline__ f2 ld_acc(const float *p) { return __builtin_nontemporal_load((const f2 *)p); }
+
+// ---- the SGD round ----------------------------------------------------------------------
+
+// LANES  lanes per rating (power of two, LANES*4 >= k_a)
+// FULL   k_a == LANES*4: every lane carries factors (no per-lane bounds test)
+// SLOW   epoch 0 of the reference: only factors [0,8) move (slow_only, mf.cpp:2834, 1230-1231)
+template <int LANES, bool FULL, bool SLOW>
+__global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
+{
+    constexpr int G = 64 / LANES;
+    constexpr unsigned NONE = 0xFFFFFFFFu, IDMASK = 0x7FFFFFFFu;
+    const int lane = threadIdx.x & 63;
+    const int lig = lane % LANES;
+    const int grp = lane / LANES;
+    const int d0 = lig * 4;
+    const int ka = a.ka;
+    const bool lane_ok = FULL || d0 < ka;
+    const bool slot1 = d0 >= 8;               // dims [8,k_a) use accumulator slot 1
+    const bool upd = lane_ok && !(SLOW && slot1);
+    const float lam_o = a.lambda_own, lam_g = a.lambda_gat, eta = a.eta;
+    const float rk0 = 0.125f, rk1 = a.rk1;
+    const f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const EntryD pad = {0u, -1, 0.0f};
+
+    // Blocks ("slots") of this round that belong to this wave's XCD: rank, rank+X, ...
+    // (xcc_rank comes from a probe launch; an XCD the probe did not see takes no work and
+    // the host's cursor check reports the unfinished blocks -- never a silent wrong answer).
+    const int rank = (int)(threadIdx.x >> 6) < a.active_waves ? a.xcc_rank[xcc_id() & 15] : -1;
+    double lsum = 0.0;
+    if (rank >= 0)
+        for (int slot = rank; slot < a.ns; slot += a.n_xcc) {
+            const long long tbeg = a.slot_task_ptr[slot];
+            const int ntask = (int)(a.slot_task_ptr[slot + 1] - tbeg);
+            for (;;) {
+                int c = 0;
+                if (lane == 0) c = atomicAdd(&a.slot_cursor[slot], 1);
+                c = __builtin_amdgcn_readfirstlane(c);
+                if (c >= ntask) break;
+
+                const TaskDescD td = a.tasks[tbeg + c];
+                const EntryD *ep = a.entries + td.off + grp;
+                const int nsteps = (int)td.nsteps;
+
+                unsigned cur = NONE;  // owner row held in registers
+                f4 o = zero4;
+                float og0 = 1.0f, og1 = 1.0f;
+                unsigned pf = NONE;   // owner row in flight for the next visit
+                f4 on = zero4;
+                f2 ogn = {1.0f, 1.0f};
+                float tsum = 0.0f;
+
+                // two entries of look-ahead: e (this step), e1 (next), e2 (being loaded)
+                EntryD e = ep[0];
+                EntryD e1 = nsteps > 1 ? ep[G] : pad;
+                if (e.gat >= 0) { // every list starts with a visit: fetch its owner row now
+                    pf = e.own & IDMASK;
+                    if (lane_ok) on = ld_row(a.own_rows + (size_t)pf * ka + d0);
+                    ogn = ld_acc(a.own_acc + (size_t)pf * 2);
+                }
+                for (int step = 0; step < nsteps; ++step) {
+                    EntryD e2 = pad;
+                    if (step + 2 < nsteps) e2 = ep[(size_t)(step + 2) * G];
+                    const bool act = e.gat >= 0;
+                    float *grow = a.gat_rows + (size_t)(act ? e.gat : 0) * ka + d0;
+                    float *gacc = a.gat_acc + (size_t)(act ? e.gat : 0) * 2;
+                    f4 g = zero4;
+                    f2 gg = {1.0f, 1.0f};
+                    if (act) { // gathered row: issued first, everything below overlaps its latency
+                        if (lane_ok) g = ld_row(grow);
+                        gg = ld_acc(gacc);
+                        const unsigned id = e.own & IDMASK;
+                        if ((e.own >> 31) && id != cur) { // a new visit: switch the owner row
+                            if (cur != NONE) {
+                                if (lane_ok) *(f4 *)(a.own_rows + (size_t)cur * ka + d0) = o;
+                                if (lig == 0) *(f2 *)(a.own_acc + (size_t)cur * 2) = f2{og0, og1};
+                            }
+                            if (pf != id) { // not prefetched (cannot happen for lists built by plan.cpp)
+                                if (lane_ok) on = ld_row(a.own_rows + (size_t)id * ka + d0);
+                                ogn = ld_acc(a.own_acc + (size_t)id * 2);
+                            }
+                            o = on;
+                            og0 = ogn.x;
+                            og1 = ogn.y;
+                            cur = id;
+                        }
+                    }
+                    // prefetch the owner row of the visit that starts at the next step
+                    if (e1.gat >= 0 && (e1.own >> 31)) {
+                        const unsigned id1 = e1.own & IDMASK;
+                        if (id1 != cur) {
+                            pf = id1;
+                            if (lane_ok) on = ld_row(a.own_rows + (size_t)id1 * ka + d0);
+                            ogn = ld_acc(a.own_acc + (size_t)id1 * 2);
+                        }
+                    }
+                    if (act) {
+                        // z = p.q (calc_z), e = r - z (prepare_for_sg_update)
+                        float z = o.x * g.x + o.y * g.y + o.z * g.z + o.w * g.w;
+                        z = group_sum<LANES>(z);
+                        const float err = e.r - z;
+                        tsum += err * err;
+
+                        // sg_update: eta scaled by rsqrt of the slot this lane's dims belong to
+                        const float eta_o = eta * __builtin_amdgcn_rsqf(slot1 ? og1 : og0);
+                        const float eta_g = eta * __builtin_amdgcn_rsqf(slot1 ? gg.y : gg.x);
+                        float so = 0.0f, sg = 0.0f;
+                        if (upd) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float ov = o[j], gv = g[j];
+                                const float go = lam_o * ov - err * gv; // both use the OLD values
+                                const float gq = lam_g * gv - err * ov;
+                                so += go * go;
+                                sg += gq * gq;
+                                o[j] = ov - eta_o * go;
+                                g[j] = gv - eta_g * gq;
+                            }
+                        }
+                        const float so0 = group_sum<LANES>(slot1 ? 0.0f : so);
+                        const float sg0 = group_sum<LANES>(slot1 ? 0.0f : sg);
+                        og0 = og0 + so0 * rk0;
+                        gg.x = gg.x + sg0 * rk0;
+                        if (!SLOW) {
+                            const float so1 = group_sum<LANES>(slot1 ? so : 0.0f);
+                            const float sg1 = group_sum<LANES>(slot1 ? sg : 0.0f);
+                            og1 = og1 + so1 * rk1;
+                            gg.y = gg.y + sg1 * rk1;
+                        }
+                        if (lane_ok) *(f4 *)grow = g;
+                        if (lig == 0) *(f2 *)gacc = gg;
+                    }
+                    e = e1;
+                    e1 = e2;
+                }
+                if (cur != NONE) {
+                    if (lane_ok) *(f4 *)(a.own_rows + (size_t)cur * ka + d0) = o;
+                    if (lig == 0) *(f2 *)(a.own_acc + (size_t)cur * 2) = f2{og0, og1};
+                }
+                if (lig == 0) lsum += (double)tsum;
+            }
+        }
+
+    // online loss of this wave -> one double atomic (Scheduler::get_loss, mf.cpp:237-241)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off);
+    if (lane == 0 && lsum != 0.0) atomicAdd(a.loss, lsum);
+}
+
+// Which XCC ids does a grid land on?  One bit per id seen (run once per trainer).
+__global__ void probe_xcc(unsigned *mask)
+{
+    if (threadIdx.x == 0) atomicOr(mask, 1u << (xcc_id() & 15));
+}
+
+// ---- metrics ------------------------------------------------------------------------
+
+// sum over the plan's ratings of (r - p.q)^2 in scaled units
+template <int LANES>
+__global__ __launch_bounds__(256) void sq_err_entries(const float *own_rows, const float *gat_rows,
+                                                      const EntryD *entries, long long n_entries,
+                                                      int ka, double *out)
+{
+    constexpr int G = 64 / LANES;
+    const int lane = threadIdx.x & 63;
+    const int lig = lane % LANES, grp = lane / LANES;
+    const int d0 = lig * 4;
+    const bool lane_ok = d0 < ka;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    double lsum = 0.0;
+    for (long long base = wave * G; base < n_entries; base += nwaves * G) {
+        long long i = base + grp;
+        float z = 0.0f, r = 0.0f;
+        bool act = false;
+        if (i < n_entries) {
+            EntryD e = entries[i];
+            act = e.gat >= 0;
+            if (act && lane_ok) {
+                f4 o = *(const f4 *)(own_rows + (size_t)(e.own & 0x7FFFFFFFu) * ka + d0);
+                f4 g = *(const f4 *)(gat_rows + (size_t)e.gat * ka + d0);
+                z = o.x * g.x + o.y * g.y + o.z * g.z + o.w * g.w;
+            }
+            r = e.r;
+        }
+        z = group_sum<LANES>(z);
+        if (act && lig == 0) {
+            float err = r - z;
+            lsum += (double)(err * err);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off);
+    if (lane == 0 && lsum != 0.0) atomicAdd(out, lsum);
+}
+
+// calc_reg2 (mf.cpp:608-633): sum_i omega[i] * |row_i|^2 for one side
+__global__ __launch_bounds__(256) void reg2_side(const float *rows, const int *omega, int nrows,
+                                                 int ka, double *out)
+{
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nth = (long long)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    for (long long i = tid; i < nrows; i += nth) {
+        int w = omega[i];
+        if (w <= 0) continue;
+        const float *r = rows + (size_t)i * ka;
+        float s = 0.0f;
+        for (int d = 0; d < ka; ++d) s += r[d] * r[d];
+        acc += (double)((float)w * s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(out, acc);
+}
+
+// mf_predict (mf.cpp:4295-4314) over (u,v) float pairs against a facade array on the
+// device: out of range -> b, NaN -> b.  One 16-lane group per pair.
+__global__ __launch_bounds__(256) void predict_pairs(const float *model, int m, int n, int k,
+                                                     float b, const float *pairs,
+                                                     long long npairs, float *out)
+{
+    const int lane = threadIdx.x & 63, lig = lane & 15, grp = lane >> 4;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const float *P = model + 5, *Q = model + 5 + (size_t)m * k;
+    for (long long base = wave * 4; base < npairs; base += nwaves * 4) {
+        long long i = base + grp;
+        float z = 0.0f;
+        bool in = false, valid = i < npairs;
+        if (valid) {
+            int u = (int)pairs[2 * i], v = (int)pairs[2 * i + 1];
+            in = u >= 0 && u < m && v >= 0 && v < n;
+            if (in) {
+                const float *p = P + (size_t)u * k, *q = Q + (size_t)v * k;
+                for (int d = lig; d < k; d += 16) z += p[d] * q[d];
+            }
+        }
+        z = group_sum<16>(z);
+        if (valid && lig == 0) out[i] = (in && z == z) ? z : b;
+    }
+}
+
+// calc_rmse (mf.cpp:4316-4331) of a facade array over mf_node ratings
+__global__ __launch_bounds__(256) void sq_err_nodes(const float *model, int m, int n, int k, float b,
+                                                    const EntryD *R, long long nnz, double *out)
+{
+    const int lane = threadIdx.x & 63, lig = lane & 15, grp = lane >> 4;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const float *P = model + 5, *Q = model + 5 + (size_t)m * k;
+    double lsum = 0.0;
+    for (long long base = wave * 4; base < nnz; base += nwaves * 4) {
+        long long i = base + grp;
+        float z = 0.0f, r = 0.0f;
+        bool in = false, valid = i < nnz;
+        if (valid) {
+            int u = (int)R[i].own, v = R[i].gat; // mf_node {u, v, r} viewed through EntryD
+            r = R[i].r;
+            in = u >= 0 && u < m && v >= 0 && v < n;
+            if (in) {
+                const float *p = P + (size_t)u * k, *q = Q + (size_t)v * k;
+                for (int d = lig; d < k; d += 16) z += p[d] * q[d];
+            }
+        }
+        z = group_sum<16>(z);
+        if (valid && lig == 0) {
+            float pred = (in && z == z) ? z : b;
+            float err = r - pred;
+            lsum += (double)(err * err);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off);
+    if (lane == 0 && lsum != 0.0) atomicAdd(out, lsum);
+}
+
+// scale_model + shrink_model + shuffle_model (mf.cpp:529-553, 1057-1074, 1027-1055):
+// out[orig][d] = rows[map[orig]][d] * f for d < k
+__global__ __launch_bounds__(256) void export_side(const float *rows, const int *map, int nrows,
+                                                   int k, int ka, float f, int do_scale, float *out)
+{
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)nrows * k;
+    const long long nth = (long long)gridDim.x * blockDim.x;
+    for (long long i = tid; i < total; i += nth) {
+        long long row = i / k;
+        int d = (int)(i - row * k);
+        float x = rows[(size_t)map[row] * ka + d];
+        out[i] = do_scale ? x * f : x;
+    }
+}
+
+__global__ void fill_f32(float *p, long long n, float v)
+{
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nth = (long long)gridDim.x * blockDim.x;
+    for (long long i = tid; i < n; i += nth) p[i] = v;
+}
+
+} // namespace mfx
+
+#include "synth.hpp"
+
+namespace mfx {
+
+__global__ __launch_bounds__(256) void synth_kernel(unsigned long long seed,
+                                                    unsigned long long shard, long long first,
+                                                    long long count, int m, int n, SynthNode *out)
+{
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nth = (long long)gridDim.x * blockDim.x;
+    for (long long i = tid; i < count; i += nth) out[i] = synth_rating(seed, shard, first + i, m, n);
+}
+
+// ---- launchers (the only symbols the host code sees) ---------------------------------
+
+template <int LANES>
+static void launch_round_t(const RoundArgs &a, int grid, hipStream_t s)
+{
+    const bool full = a.ka == LANES * 4;
+    if (full && a.slow_only)
+        hipLaunchKernelGGL((sgd_round<LANES, true, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (full)
+        hipLaunchKernelGGL((sgd_round<LANES, true, false>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.slow_only)
+        hipLaunchKernelGGL((sgd_round<LANES, false, true>), dim3(grid), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((sgd_round<LANES, false, false>), dim3(grid), dim3(256), 0, s, a);
+}
+
+hipError_t launch_sgd_round(int lanes, const RoundArgs &a, int grid, hipStream_t s)
+{
+    switch (lanes) {
+    case 2: launch_round_t<2>(a, grid, s); break;
+    case 4: launch_round_t<4>(a, grid, s); break;
+    case 8: launch_round_t<8>(a, grid, s); break;
+    case 16: launch_round_t<16>(a, grid, s); break;
+    case 32: launch_round_t<32>(a, grid, s); break;
+    case 64: launch_round_t<64>(a, grid, s); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_probe_xcc(unsigned *mask, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(probe_xcc, dim3(grid), dim3(64), 0, s, mask);
+    return hipGetLastError();
+}
+
+hipError_t launch_sq_err_entries(int lanes, const float *own_rows, const float *gat_rows,
+                                 const EntryD *entries, long long n_entries, int ka, double *out,
+                                 int grid, hipStream_t s)
+{
+#define MFX_CASE(L)                                                                             \
+    case L:                                                                                     \
+        hipLaunchKernelGGL(sq_err_entries<L>, dim3(grid), dim3(256), 0, s, own_rows, gat_rows,  \
+                           entries, n_entries, ka, out);                                        \
+        break;
+    switch (lanes) {
+        MFX_CASE(2) MFX_CASE(4) MFX_CASE(8) MFX_CASE(16) MFX_CASE(32) MFX_CASE(64)
+    default: return hipErrorInvalidValue;
+    }
+#undef MFX_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_reg2(const float *rows, const int *omega, int nrows, int ka, double *out,
+                       int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(reg2_side, dim3(grid), dim3(256), 0, s, rows, omega, nrows, ka, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_predict(const float *model, int m, int n, int k, float b, const float *pairs,
+                          long long npairs, float *out, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(predict_pairs, dim3(grid), dim3(256), 0, s, model, m, n, k, b, pairs, npairs,
+                       out);
+    return hipGetLastError();
+}
+
+hipError_t launch_sq_err_nodes(const float *model, int m, int n, int k, float b, const EntryD *R,
+                               long long nnz, double *out, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(sq_err_nodes, dim3(grid), dim3(256), 0, s, model, m, n, k, b, R, nnz, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_export(const float *rows, const int *map, int nrows, int k, int ka, float f,
+                         int do_scale, float *out, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(export_side, dim3(grid), dim3(256), 0, s, rows, map, nrows, k, ka, f,
+                       do_scale, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill(float *p, long long n, float v, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(fill_f32, dim3(grid), dim3(256), 0, s, p, n, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth(unsigned long long seed, unsigned long long shard, long long first,
+                        long long count, int m, int n, void *out, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(synth_kernel, dim3(grid), dim3(256), 0, s, seed, shard, first, count, m, n,
+                       (SynthNode *)out);
+    return hipGetLastError();
+}
+
+} // namespace mfx

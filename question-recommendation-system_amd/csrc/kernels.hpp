@@ -1,0 +1,47 @@
+// kernels.hpp -- launch interface between the host pipeline and kernels.hip.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace mfx {
+
+// device views of plan.hpp's Entry / TaskDesc (same layout)
+struct EntryD { uint32_t own; int32_t gat; float r; };
+struct TaskDescD { uint64_t off; uint32_t nsteps; uint32_t pad; };
+
+// Arguments of one SGD round (= one launch = NS stripe-disjoint blocks).
+struct RoundArgs {
+    float *own_rows;  // factors of the owner side   (n_own x ka)
+    float *gat_rows;  // factors of the gathered side (n_gat x ka)
+    float *own_acc;   // Adagrad slots, 2 per row (reference PG/QG, mf.cpp:2835)
+    float *gat_acc;
+    const EntryD *entries;
+    const TaskDescD *tasks;
+    const long long *slot_task_ptr; // ns+1 task offsets of this round
+    int *slot_cursor;               // ns ints, zero before the launch
+    double *loss;                   // sum of e^2 (scaled units), accumulated
+    float lambda_own, lambda_gat, eta, rk1;
+    int ka, slow_only, ns;
+    int n_xcc;                      // XCDs that take work
+    int active_waves;               // waves of a workgroup that take work (1..4)
+    signed char xcc_rank[16];       // HW_REG_XCC_ID -> rank in [0, n_xcc), -1 = takes no work
+};
+
+hipError_t launch_sgd_round(int lanes, const RoundArgs &a, int grid, hipStream_t s);
+hipError_t launch_probe_xcc(unsigned *mask, int grid, hipStream_t s);
+hipError_t launch_sq_err_entries(int lanes, const float *own_rows, const float *gat_rows,
+                                 const EntryD *entries, long long n_entries, int ka, double *out,
+                                 int grid, hipStream_t s);
+hipError_t launch_reg2(const float *rows, const int *omega, int nrows, int ka, double *out,
+                       int grid, hipStream_t s);
+hipError_t launch_predict(const float *model, int m, int n, int k, float b, const float *pairs,
+                          long long npairs, float *out, int grid, hipStream_t s);
+hipError_t launch_sq_err_nodes(const float *model, int m, int n, int k, float b, const EntryD *R,
+                               long long nnz, double *out, int grid, hipStream_t s);
+hipError_t launch_export(const float *rows, const int *map, int nrows, int k, int ka, float f,
+                         int do_scale, float *out, int grid, hipStream_t s);
+hipError_t launch_fill(float *p, long long n, float v, int grid, hipStream_t s);
+hipError_t launch_synth(unsigned long long seed, unsigned long long shard, long long first,
+                        long long count, int m, int n, void *out, int grid, hipStream_t s);
+
+} // namespace mfx

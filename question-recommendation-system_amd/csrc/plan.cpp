@@ -1,0 +1,380 @@
+// plan.cpp -- see plan.hpp.
+#include "plan.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <queue>
+#include <stdexcept>
+#include <thread>
+
+#include "rng.hpp"
+
+namespace mfx {
+
+int lanes_for(int ka)
+{
+    int need = (ka + 3) / 4, l = 2;
+    while (l < need) l <<= 1;
+    return l;
+}
+
+void parallel_ranges(long long n, int threads,
+                     const std::function<void(long long, long long, int)> &fn)
+{
+    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    if (threads <= 0) threads = 1;
+    if (n < 4096 || threads == 1) {
+        fn(0, n, 0);
+        return;
+    }
+    std::vector<std::thread> pool;
+    long long chunk = (n + threads - 1) / threads;
+    for (int t = 0; t < threads; ++t) {
+        long long b = t * chunk, e = std::min(n, b + chunk);
+        if (b >= e) break;
+        pool.emplace_back(fn, b, e, t);
+    }
+    for (auto &th : pool) th.join();
+}
+
+void gen_random_map(int size, std::vector<int> &map)
+{
+    // srand(0); iota; std::random_shuffle  (reference mf/mf.cpp:1009-1017)
+    GlibcRand rng(0);
+    map.resize(size);
+    for (int i = 0; i < size; ++i) map[i] = i;
+    for (int i = 1; i < size; ++i) {
+        int j = rng.next() % (i + 1);
+        if (i != j) std::swap(map[i], map[j]);
+    }
+}
+
+// mean / standard deviation in double (reference mf/mf.cpp:462-484).  Fixed 1M-rating
+// chunks summed in order, so the result does not depend on the thread count.
+static void collect_info(const Node *R, long long nnz, int threads, float &avg, float &sd)
+{
+    const long long CH = 1 << 20;
+    long long nch = (nnz + CH - 1) / CH;
+    std::vector<double> s1(nch), s2(nch);
+    parallel_ranges(nch, threads, [&](long long b, long long e, int) {
+        for (long long c = b; c < e; ++c) {
+            double a = 0, q = 0;
+            long long hi = std::min(nnz, (c + 1) * CH);
+            for (long long i = c * CH; i < hi; ++i) {
+                a += (double)R[i].r;
+                q += (double)R[i].r * R[i].r;
+            }
+            s1[c] = a;
+            s2[c] = q;
+        }
+    });
+    double ex = 0, ex2 = 0;
+    for (long long c = 0; c < nch; ++c) {
+        ex += s1[c];
+        ex2 += s2[c];
+    }
+    ex /= (double)nnz;
+    ex2 /= (double)nnz;
+    avg = (float)ex;
+    sd = (float)std::sqrt(ex2 - ex * ex);
+}
+
+namespace {
+
+struct Rat { uint32_t own; uint32_t gat; float r; };
+
+struct Visit { uint32_t own; uint32_t start; uint32_t len; };
+
+struct BlockOut {
+    std::vector<Entry> entries;
+    std::vector<TaskDesc> tasks; // offsets relative to this block
+    long long hot = 0, padding = 0;
+};
+
+// Pack one class of visits into tasks whose lane-group lists hold about `target` ratings:
+// longest-processing-time-first into G*ntasks lists, lists of similar load share a task.
+void pack_class(const Rat *rat, const std::vector<Visit> &visits, size_t vbeg, size_t vend, int G,
+                int target, BlockOut &out)
+{
+    if (vbeg >= vend) return;
+    long long L = 0;
+    for (size_t i = vbeg; i < vend; ++i) L += visits[i].len;
+    target = std::max<long long>(target, visits[vbeg].len); // visits are sorted, longest first
+    long long ntasks = (L + (long long)G * target - 1) / ((long long)G * target);
+    if (ntasks < 1) ntasks = 1;
+    const long long NG = ntasks * G;
+    typedef std::pair<uint32_t, uint32_t> LB; // (load, list)
+    std::priority_queue<LB, std::vector<LB>, std::greater<LB>> heap;
+    for (long long b = 0; b < NG; ++b) heap.push({0u, (uint32_t)b});
+    std::vector<std::vector<uint32_t>> list_visits(NG);
+    std::vector<uint32_t> load(NG, 0);
+    for (size_t vi = vbeg; vi < vend; ++vi) {
+        LB top = heap.top();
+        heap.pop();
+        list_visits[top.second].push_back((uint32_t)vi);
+        load[top.second] = top.first + visits[vi].len;
+        heap.push({load[top.second], top.second});
+    }
+    std::vector<uint32_t> order(NG);
+    for (long long b = 0; b < NG; ++b) order[b] = (uint32_t)b;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](uint32_t a, uint32_t b) { return load[a] > load[b]; });
+    for (long long t = 0; t < ntasks; ++t) {
+        uint32_t nsteps = load[order[t * G]];
+        if (nsteps == 0) break; // the remaining lists are empty
+        TaskDesc td;
+        td.off = out.entries.size();
+        td.nsteps = nsteps;
+        td.pad = 0;
+        size_t base = out.entries.size();
+        out.entries.resize(base + (size_t)nsteps * G, Entry{0u, -1, 0.0f});
+        for (int g = 0; g < G; ++g) {
+            uint32_t lst = order[t * G + g];
+            uint32_t step = 0;
+            for (uint32_t vi : list_visits[lst]) {
+                const Visit &v = visits[vi];
+                for (uint32_t x = 0; x < v.len; ++x, ++step) {
+                    const Rat &rr = rat[v.start + x];
+                    Entry &e = out.entries[base + (size_t)step * G + g];
+                    e.own = rr.own | (x == 0 ? 0x80000000u : 0u); // first rating of a visit
+                    e.gat = (int32_t)rr.gat;
+                    e.r = rr.r;
+                }
+            }
+            out.padding += nsteps - step;
+        }
+        out.tasks.push_back(td);
+    }
+}
+
+// Cut one (owner-stripe, gather-stripe) block into wavefront tasks.
+void pack_block(const Rat *rat, long long L, int G, int target, BlockOut &out)
+{
+    if (L == 0) return;
+    // runs of equal owner id = visits; a run longer than two task lengths is cut into chains
+    // that may run in different lane groups (each works on its own copy of the owner row and
+    // the last one to finish wins -- measured to cost less RMSE than exchanging the row
+    // through memory every few ratings, DESIGN.md "Hot rows")
+    std::vector<Visit> visits;
+    const long long hot_len = 2LL * target;
+    for (long long i = 0; i < L;) {
+        long long j = i;
+        while (j < L && rat[j].own == rat[i].own) ++j;
+        long long len = j - i;
+        if (len > hot_len) {
+            long long nch = (len + target - 1) / target;
+            long long per = (len + nch - 1) / nch;
+            for (long long s = i; s < j; s += per)
+                visits.push_back({rat[i].own, (uint32_t)s, (uint32_t)std::min(per, j - s)});
+            out.hot++;
+        } else {
+            visits.push_back({rat[i].own, (uint32_t)i, (uint32_t)len});
+        }
+        i = j;
+    }
+    std::stable_sort(visits.begin(), visits.end(),
+                     [](const Visit &a, const Visit &b) { return a.len > b.len; });
+
+    // Graded task sizes: the first half of the work goes into full-size tasks, then a
+    // quarter at half size, ... so the waves that drain the block's queue last are holding
+    // short tasks (the launch ends when the slowest wave does).
+    const double frac[4] = {0.5, 0.75, 0.875, 1.0};
+    size_t vbeg = 0;
+    long long acc = 0;
+    for (int c = 0; c < 4; ++c) {
+        size_t vend = vbeg;
+        if (c == 3) {
+            vend = visits.size();
+        } else {
+            while (vend < visits.size() && acc < (long long)(frac[c] * (double)L)) acc += visits[vend++].len;
+        }
+        pack_class(rat, visits, vbeg, vend, G, std::max(4, target >> c), out);
+        vbeg = vend;
+    }
+}
+
+} // namespace
+
+void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cfg, Plan &p)
+{
+    if (nnz <= 0 || m <= 0 || n <= 0) throw std::invalid_argument("empty problem");
+    if (cfg.k < 1) throw std::invalid_argument("number of factors must be greater than zero");
+    int threads = cfg.threads > 0 ? cfg.threads : (int)std::thread::hardware_concurrency();
+    if (threads < 1) threads = 1;
+
+    p.m = m;
+    p.n = n;
+    p.k = cfg.k;
+    p.ka = k_aligned(cfg.k);
+    p.nnz = nnz;
+    p.ns = std::max(1, cfg.stripes);
+    p.lanes = cfg.lanes;
+    p.groups = 64 / cfg.lanes;
+    p.owner_is_q = cfg.owner_side == 0 ? (m >= n) : cfg.owner_side == 2;
+
+    collect_info(R, nnz, threads, p.avg, p.std_dev);
+    p.scale = std::max((float)1e-4, p.std_dev); // reference mf/mf.cpp:2999
+    p.inv_scale = (float)1.0 / p.scale;         // reference mf/mf.cpp:3010
+
+    if (cfg.identity_maps) {
+        p.p_map.resize(m);
+        p.q_map.resize(n);
+        for (int i = 0; i < m; ++i) p.p_map[i] = i;
+        for (int i = 0; i < n; ++i) p.q_map[i] = i;
+    } else {
+        std::thread tq([&] { gen_random_map(n, p.q_map); });
+        gen_random_map(m, p.p_map);
+        tq.join();
+    }
+
+    // validate ids, relabel (shuffle_problem, mf.cpp:775-791), scale (mf.cpp:517-527),
+    // count rows (omega, mf.cpp:815-816) and bucket by block
+    const int NS = p.ns;
+    const int n_own = p.owner_is_q ? n : m, n_gat = p.owner_is_q ? m : n;
+    const int seg_own = (n_own + NS - 1) / NS, seg_gat = (n_gat + NS - 1) / NS;
+    const int NB = NS * NS;
+    for (long long i = 0; i < nnz; ++i)
+        if (R[i].u < 0 || R[i].u >= m || R[i].v < 0 || R[i].v >= n)
+            throw std::invalid_argument("rating with id outside [0,m) x [0,n)");
+
+    p.omega_p.assign(m, 0);
+    p.omega_q.assign(n, 0);
+    std::vector<Rat> rat(nnz);
+    std::vector<uint16_t> blk(nnz);
+    const bool do_scale = p.inv_scale != 1.0f;
+    parallel_ranges(nnz, threads, [&](long long b, long long e, int) {
+        for (long long i = b; i < e; ++i) {
+            uint32_t u = (uint32_t)p.p_map[R[i].u], v = (uint32_t)p.q_map[R[i].v];
+            Rat x;
+            x.own = p.owner_is_q ? v : u;
+            x.gat = p.owner_is_q ? u : v;
+            x.r = do_scale ? R[i].r * p.inv_scale : R[i].r;
+            rat[i] = x;
+            blk[i] = (uint16_t)((x.own / seg_own) * NS + x.gat / seg_gat);
+        }
+    });
+    if (NB > 65535) throw std::invalid_argument("too many stripes");
+    std::vector<long long> bptr(NB + 1, 0);
+    for (long long i = 0; i < nnz; ++i) {
+        bptr[blk[i] + 1]++;
+        p.omega_p[p.owner_is_q ? rat[i].gat : rat[i].own]++;
+        p.omega_q[p.owner_is_q ? rat[i].own : rat[i].gat]++;
+    }
+    for (int b = 0; b < NB; ++b) bptr[b + 1] += bptr[b];
+    std::vector<Rat> sorted(nnz);
+    {
+        std::vector<long long> cur(bptr.begin(), bptr.end() - 1);
+        for (long long i = 0; i < nnz; ++i) sorted[cur[blk[i]]++] = rat[i];
+    }
+    std::vector<Rat>().swap(rat);
+    std::vector<uint16_t>().swap(blk);
+
+    // per-block sort by (owner, gathered) and task packing, blocks in parallel
+    std::vector<BlockOut> outs(NB);
+    const int G = p.groups;
+    {
+        std::vector<int> blocks(NB);
+        for (int b = 0; b < NB; ++b) blocks[b] = b;
+        std::sort(blocks.begin(), blocks.end(), [&](int a, int b) {
+            return bptr[a + 1] - bptr[a] > bptr[b + 1] - bptr[b];
+        });
+        std::vector<std::thread> pool;
+        std::atomic<int> next(0);
+        auto work = [&]() {
+            for (;;) {
+                int idx = next.fetch_add(1);
+                if (idx >= NB) break;
+                int b = blocks[idx];
+                Rat *beg = sorted.data() + bptr[b];
+                long long L = bptr[b + 1] - bptr[b];
+                std::sort(beg, beg + L, [](const Rat &x, const Rat &y) {
+                    return x.own != y.own ? x.own < y.own : x.gat < y.gat;
+                });
+                int target = cfg.task_steps;
+                if (target <= 0) {
+                    // about 1.5 full-size tasks per wave; the graded tail (pack_block) keeps
+                    // the end of the launch short
+                    long long t = 2 * L / ((long long)G * 3 * std::max(1, cfg.waves_per_stripe));
+                    target = (int)std::min<long long>(256, std::max<long long>(16, t));
+                }
+                pack_block(beg, L, G, target, outs[b]);
+            }
+        };
+        int nt = std::min(threads, NB);
+        for (int t = 0; t < nt; ++t) pool.emplace_back(work);
+        for (auto &th : pool) th.join();
+    }
+    std::vector<Rat>().swap(sorted);
+
+    // concatenate in (round, slot) order: round r, slot s -> owner stripe s,
+    // gathered stripe (s + r) mod NS, so the NS slots of a round are stripe-disjoint
+    size_t tot_e = 0, tot_t = 0;
+    for (auto &o : outs) {
+        tot_e += o.entries.size();
+        tot_t += o.tasks.size();
+        p.n_hot_rows += o.hot;
+        p.n_padding += o.padding;
+    }
+    p.entries.clear();
+    p.entries.reserve(tot_e);
+    p.tasks.clear();
+    p.tasks.reserve(tot_t);
+    p.slot_task_ptr.assign((size_t)NB + 1, 0);
+    for (int r = 0; r < NS; ++r)
+        for (int s = 0; s < NS; ++s) {
+            int b = s * NS + (s + r) % NS;
+            BlockOut &o = outs[b];
+            uint64_t ebase = p.entries.size();
+            p.entries.insert(p.entries.end(), o.entries.begin(), o.entries.end());
+            for (TaskDesc td : o.tasks) {
+                td.off += ebase;
+                p.tasks.push_back(td);
+            }
+            p.slot_task_ptr[(size_t)r * NS + s + 1] = (long long)p.tasks.size();
+            std::vector<Entry>().swap(o.entries);
+            std::vector<TaskDesc>().swap(o.tasks);
+        }
+}
+
+void init_factors(const Plan &p, const int *omega_q_override, std::vector<float> &P,
+                  std::vector<float> &Q, int threads)
+{
+    // One minstd_rand0 stream, P rows then Q rows in internal order, k draws per seen row
+    // scaled by sqrt(1/k); unseen rows NaN; padding zero (reference mf/mf.cpp:952-1007).
+    const int k = p.k, ka = p.ka;
+    const float s = (float)std::sqrt(1.0 / k);
+    P.assign((size_t)p.m * ka, 0.0f);
+    Q.assign((size_t)p.n * ka, 0.0f);
+    const int *oq = omega_q_override ? omega_q_override : p.omega_q.data();
+    // stream position of every row = k * (seen rows before it)
+    std::vector<uint64_t> pos((size_t)p.m + p.n);
+    uint64_t seen = 0;
+    for (int i = 0; i < p.m; ++i) {
+        pos[i] = seen;
+        seen += p.omega_p[i] > 0;
+    }
+    for (int i = 0; i < p.n; ++i) {
+        pos[(size_t)p.m + i] = seen;
+        seen += oq[i] > 0;
+    }
+    const long long rows = (long long)p.m + p.n;
+    parallel_ranges(rows, threads, [&](long long b, long long e, int) {
+        Minstd0 gen(Minstd0::jump(1u, pos[b] * (uint64_t)k));
+        for (long long i = b; i < e; ++i) {
+            bool isP = i < p.m;
+            long long row = isP ? i : i - p.m;
+            float *dst = (isP ? P.data() : Q.data()) + row * ka;
+            bool seen_row = isP ? p.omega_p[row] > 0 : oq[row] > 0;
+            if (seen_row)
+                for (int d = 0; d < k; ++d) dst[d] = (float)(gen.unit() * s);
+            else
+                for (int d = 0; d < k; ++d) dst[d] = std::numeric_limits<float>::quiet_NaN();
+        }
+    });
+}
+
+} // namespace mfx

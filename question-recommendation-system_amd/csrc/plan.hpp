@@ -1,0 +1,72 @@
+// plan.hpp -- host-side pre-processing of one training problem into the layout the
+// SGD kernel streams from HBM.
+//
+// Mirrors the reference's fpsg() prologue (reference mf/mf.cpp:2972-3016):
+// collect_info -> gen_random_map -> shuffle_problem -> scale_problem -> grid_problem,
+// with grid_problem's nr_bins^2 CPU blocks replaced by a stripes^2 grid of
+// (owner-stripe, gather-stripe) blocks cut into wavefront tasks.
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <vector>
+
+namespace mfx {
+
+struct Node { int u; int v; float r; }; // = mf_node (reference mf/mf.h:36-41)
+
+// One rating as the kernel reads it.  `own` = id on the register-resident ("owner")
+// side, bit 31 set when the owner row must be (re)loaded before this rating;
+// `gat` = id on the gathered side, -1 for a padding slot.
+struct Entry { uint32_t own; int32_t gat; float r; };
+static_assert(sizeof(Entry) == 12, "Entry must stay 12 bytes (mf_node sized)");
+
+// One wavefront task: `nsteps` steps of G = 64/lanes ratings, stored step-major
+// (entry index = off + step*G + group).
+struct TaskDesc { uint64_t off; uint32_t nsteps; uint32_t pad; };
+
+struct PlanConfig {
+    int k = 8;
+    int stripes = 8;          // NS
+    int lanes = 2;            // lanes per rating (power of two)
+    int task_steps = 0;       // 0 = auto
+    int owner_side = 0;       // 0 auto, 1 users, 2 items
+    bool identity_maps = false;
+    int waves_per_stripe = 256; // for auto task sizing
+    int threads = 0;          // host worker threads, 0 = hardware_concurrency
+};
+
+struct Plan {
+    int m = 0, n = 0, k = 0, ka = 0;
+    long long nnz = 0;
+    float avg = 0, std_dev = 0, scale = 1, inv_scale = 1;
+    bool owner_is_q = true;
+    int ns = 8, lanes = 2, groups = 32;
+    std::vector<int> p_map, q_map;       // original id -> internal id
+    std::vector<int> omega_p, omega_q;   // ratings per internal row
+    std::vector<Entry> entries;
+    std::vector<TaskDesc> tasks;
+    std::vector<long long> slot_task_ptr; // ns*ns+1, ordered (round, slot)
+    long long n_hot_rows = 0;
+    long long n_padding = 0;
+};
+
+// number of floats per padded row: 8*ceil(k/8) (reference mf/mf.cpp:959)
+inline int k_aligned(int k) { return (k + 7) / 8 * 8; }
+
+// lanes per rating for a padded width: next power of two >= ka/4
+int lanes_for(int ka);
+
+// Throws std::runtime_error / std::bad_alloc; callers at the C boundary catch.
+void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cfg, Plan &out);
+
+// init_model (reference mf/mf.cpp:952-1007) in internal ids, padded stride ka.
+void init_factors(const Plan &plan, const int *omega_q_override, std::vector<float> &P,
+                  std::vector<float> &Q, int threads);
+
+void gen_random_map(int size, std::vector<int> &map); // reference mf/mf.cpp:1009-1017
+
+// run fn(begin,end) over [0,n) on `threads` std::threads
+void parallel_ranges(long long n, int threads, const std::function<void(long long, long long, int)> &fn);
+
+} // namespace mfx

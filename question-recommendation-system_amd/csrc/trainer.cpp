@@ -1,0 +1,819 @@
+// trainer.cpp -- the mfx_* C-ABI (include/mfx.h) over the HIP kernels.
+//
+// Host orchestration that replaces the reference's fpsg()/fpsg_core() driver
+// (reference mf/mf.cpp:2774-3042): no worker threads, no mutex scheduler -- an epoch is
+// `stripes` kernel launches on one HIP stream.
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mfx.h"
+#include "kernels.hpp"
+#include "plan.hpp"
+#include "synth.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(MFX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+int env_int(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count)
+    {
+        release();
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc((void **)&p, count * sizeof(T));
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+int grid_for(long long work_items_per_thread_total, int cu)
+{
+    long long blocks = (work_items_per_thread_total + 255) / 256;
+    long long cap = (long long)cu * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+} // namespace
+
+struct mfx_trainer {
+    mfx_options opt;
+    mfx::Plan plan; // host copy (entries/tasks dropped after upload)
+    int device = 0, cu_count = 256, xcd_count = 8, wg_per_cu = 2, wgs_per_xcd = 64, waves_per_wg = 4;
+    signed char xcc_rank[16];
+    hipStream_t stream = nullptr;
+    long long n_entries = 0, n_tasks = 0;
+    float lambda_p = 0, lambda_q = 0; // scaled (reference mf/mf.cpp:2805-2806)
+    float rk1 = 0.125f;
+
+    DevBuf<mfx::EntryD> dEntries;
+    DevBuf<mfx::TaskDescD> dTasks;
+    DevBuf<long long> dSlotPtr;
+    DevBuf<int> dSlotState; // per round: cursor[ns]
+    DevBuf<double> dScalars; // [0] epoch loss, [1] scratch
+    DevBuf<int> dOmegaP, dOmegaQ, dPmap, dQmap;
+    DevBuf<float> oP, oQ, oPG, oQG; // owned factor storage
+    float *dP = nullptr, *dQ = nullptr, *dPG = nullptr, *dQG = nullptr;
+    bool model_ready = false;
+    long long epochs_done = 0;
+    double last_loss = 0;
+    bool loss_pending = false;
+
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+
+    ~mfx_trainer()
+    {
+        for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int mfx_abi_version(void) { return MFX_ABI_VERSION; }
+
+const char *mfx_last_error(void) { return g_err.c_str(); }
+
+int mfx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void mfx_default_options(mfx_options *o)
+{
+    memset(o, 0, sizeof(*o));
+    o->k = 8; // mf_get_default_param, reference mf/mf.cpp:4538-4557
+    o->lambda_p2 = 0.1f;
+    o->lambda_q2 = 0.1f;
+    o->eta = 0.1f;
+    o->device = -1;
+}
+
+// options -> plan configuration (shared by the device trainer and the host-only plan)
+// Launch width.  The gathered side is updated lock-free, so the number of ratings in flight
+// per XCD is capped at (rows of one gathered stripe) / conflict_div: beyond that, lost
+// updates on shared rows start to cost final RMSE (measured, DESIGN.md "Concurrency cap").
+static int wgs_per_xcd_for(const mfx_options &opt, int m, int n, int ns, int cu_per_xcd,
+                           int *waves_per_wg)
+{
+    *waves_per_wg = 4;
+    if (opt.wg_per_cu > 0) return opt.wg_per_cu * cu_per_xcd;
+    int env = env_int("MFX_WG_PER_CU", 0);
+    if (env > 0) return env * cu_per_xcd;
+    const int ka = mfx::k_aligned(opt.k);
+    const int G = 64 / mfx::lanes_for(ka);
+    const bool owner_is_q = opt.owner_side == 0 ? (m >= n) : opt.owner_side == 2;
+    const long long n_gat = owner_is_q ? m : n;
+    const long long stripe_rows = (n_gat + ns - 1) / ns;
+    const int div = std::max(1, env_int("MFX_CONFLICT_DIV", 8));
+    long long waves = stripe_rows / ((long long)div * G);
+    if (waves < 4) { // tiny problem: one workgroup per XCD with 1..3 live waves
+        *waves_per_wg = (int)std::max<long long>(1, waves);
+        return 1;
+    }
+    long long wgs = (waves + 3) / 4;
+    const long long cap = (long long)cu_per_xcd * std::max(1, env_int("MFX_MAX_WG_PER_CU", 8));
+    if (wgs > cap) wgs = cap;
+    if (wgs < 1) wgs = 1;
+    return (int)wgs;
+}
+
+static mfx::PlanConfig plan_config(const mfx_options &opt, int stripes, int wgs_per_xcd, int waves_per_wg)
+{
+    mfx::PlanConfig cfg;
+    cfg.k = opt.k;
+    cfg.stripes = stripes;
+    cfg.lanes = mfx::lanes_for(mfx::k_aligned(opt.k));
+    cfg.task_steps = opt.task_steps > 0 ? opt.task_steps : env_int("MFX_TASK_STEPS", 0);
+    cfg.owner_side = opt.owner_side;
+    cfg.identity_maps = opt.identity_maps != 0;
+    cfg.waves_per_stripe = wgs_per_xcd * waves_per_wg;
+    cfg.threads = env_int("MFX_HOST_THREADS", 0);
+    return cfg;
+}
+
+static int check_options(const mfx_options &opt)
+{
+    // check_parameter, reference mf/mf.cpp:3115-3184
+    if (opt.k < 1) return fail(MFX_E_ARG, "number of factors must be greater than zero");
+    if (opt.lambda_p2 < 0 || opt.lambda_q2 < 0)
+        return fail(MFX_E_ARG, "regularization coefficient must be non-negative");
+    if (!(opt.eta > 0)) return fail(MFX_E_ARG, "learning rate must be greater than zero");
+    if (mfx::k_aligned(opt.k) > 256)
+        return fail(MFX_E_UNSUPPORTED, "k > 256 is not supported by the gfx950 kernel family yet");
+    return MFX_OK;
+}
+
+static int create_impl(const mfx::Node *R, long long nnz, int m, int n, const mfx_options *opt_in,
+                       mfx_trainer **out)
+{
+    if (!out) return fail(MFX_E_ARG, "null output handle");
+    *out = nullptr;
+    if (!opt_in) return fail(MFX_E_ARG, "null options");
+    mfx_options opt = *opt_in;
+    if (int rc0 = check_options(opt)) return rc0;
+    if (!R || nnz <= 0 || m <= 0 || n <= 0) return fail(MFX_E_EMPTY, "train on an empty training set");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(MFX_E_HIP, "no HIP device: the MI355X path cannot run (there is no CPU fallback)");
+    int dev = opt.device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    if (dev >= ndev) return fail(MFX_E_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+
+    mfx_trainer *t = new (std::nothrow) mfx_trainer();
+    if (!t) return fail(MFX_E_NOMEM, "out of host memory");
+    t->opt = opt;
+    t->device = dev;
+    t->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {
+        // which XCC ids does a grid land on?  (probe launch, once per trainer)
+        DevBuf<unsigned> dMask;
+        unsigned mask = 0;
+        hipError_t e = dMask.alloc(1);
+        if (e == hipSuccess) e = hipMemset(dMask.p, 0, sizeof(unsigned));
+        if (e == hipSuccess) e = mfx::launch_probe_xcc(dMask.p, t->cu_count * 4, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(&mask, dMask.p, sizeof(unsigned), hipMemcpyDeviceToHost);
+        if (e != hipSuccess || mask == 0) {
+            delete t;
+            return fail(MFX_E_HIP, std::string("XCC probe failed: ") + hipGetErrorString(e));
+        }
+        int rank = 0;
+        for (int i = 0; i < 16; ++i) t->xcc_rank[i] = (mask >> i) & 1 ? (signed char)rank++ : (signed char)-1;
+        t->xcd_count = rank;
+    }
+    const int stripes = opt.stripes > 0 ? opt.stripes : env_int("MFX_STRIPES", t->xcd_count);
+    const int cu_per_xcd = std::max(1, t->cu_count / t->xcd_count);
+    t->wgs_per_xcd = wgs_per_xcd_for(opt, m, n, stripes, cu_per_xcd, &t->waves_per_wg);
+    t->wg_per_cu = (t->wgs_per_xcd + cu_per_xcd - 1) / cu_per_xcd;
+
+    mfx::PlanConfig cfg = plan_config(opt, stripes, t->wgs_per_xcd, t->waves_per_wg);
+
+    try {
+        mfx::build_plan(R, nnz, m, n, cfg, t->plan);
+    } catch (const std::bad_alloc &) {
+        delete t;
+        return fail(MFX_E_NOMEM, "out of host memory while building the plan");
+    } catch (const std::exception &e) {
+        delete t;
+        return fail(MFX_E_ARG, e.what());
+    }
+    mfx::Plan &p = t->plan;
+    t->lambda_p = opt.lambda_p2 / p.scale;
+    t->lambda_q = opt.lambda_q2 / p.scale;
+    t->rk1 = (opt.rk_mode == 1 && p.ka > 8) ? (float)1.0 / (p.ka - 8) : 0.125f;
+    t->n_entries = (long long)p.entries.size();
+    t->n_tasks = (long long)p.tasks.size();
+
+    int rc = MFX_OK;
+    auto up = [&]() -> int {
+        HIP_TRY(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+        HIP_TRY(t->dEntries.alloc(p.entries.size()));
+        HIP_TRY(t->dTasks.alloc(p.tasks.size()));
+        HIP_TRY(t->dSlotPtr.alloc(p.slot_task_ptr.size()));
+        HIP_TRY(t->dSlotState.alloc((size_t)p.ns * p.ns));
+        HIP_TRY(t->dScalars.alloc(4));
+        HIP_TRY(t->dOmegaP.alloc(m));
+        HIP_TRY(t->dOmegaQ.alloc(n));
+        HIP_TRY(t->dPmap.alloc(m));
+        HIP_TRY(t->dQmap.alloc(n));
+        HIP_TRY(hipMemcpy(t->dEntries.p, p.entries.data(), p.entries.size() * sizeof(mfx::Entry),
+                          hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t->dTasks.p, p.tasks.data(), p.tasks.size() * sizeof(mfx::TaskDesc),
+                          hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t->dSlotPtr.p, p.slot_task_ptr.data(),
+                          p.slot_task_ptr.size() * sizeof(long long), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t->dOmegaP.p, p.omega_p.data(), (size_t)m * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t->dOmegaQ.p, p.omega_q.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t->dPmap.p, p.p_map.data(), (size_t)m * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t->dQmap.p, p.q_map.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(t->dScalars.p, 0, 4 * sizeof(double)));
+        return MFX_OK;
+    };
+    rc = up();
+    if (rc != MFX_OK) {
+        delete t;
+        return rc;
+    }
+    std::vector<mfx::Entry>().swap(p.entries);
+    std::vector<mfx::TaskDesc>().swap(p.tasks);
+    *out = t;
+    return MFX_OK;
+}
+
+int mfx_trainer_create(const mfx_node *R_host, long long nnz, int m, int n, const mfx_options *opt,
+                       mfx_trainer **out)
+{
+    try {
+        return create_impl((const mfx::Node *)R_host, nnz, m, n, opt, out);
+    } catch (const std::exception &e) {
+        return fail(MFX_E_STATE, e.what());
+    } catch (...) {
+        return fail(MFX_E_STATE, "unknown failure");
+    }
+}
+
+int mfx_trainer_create_device(const void *R_dev, long long nnz, int m, int n, const mfx_options *opt,
+                              mfx_trainer **out)
+{
+    // Round 1: the stripe/task layout is built on the host, so device-resident ratings
+    // take one trip over PCIe here (one-off, outside every timed region).
+    if (!R_dev || nnz <= 0) return fail(MFX_E_EMPTY, "train on an empty training set");
+    try {
+        std::vector<mfx::Node> host((size_t)nnz);
+        HIP_TRY(hipMemcpy(host.data(), R_dev, (size_t)nnz * sizeof(mfx::Node), hipMemcpyDeviceToHost));
+        return create_impl(host.data(), nnz, m, n, opt, out);
+    } catch (const std::exception &e) {
+        return fail(MFX_E_NOMEM, e.what());
+    }
+}
+
+void mfx_trainer_destroy(mfx_trainer *t)
+{
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    if (t->stream) (void)hipStreamSynchronize(t->stream);
+    delete t;
+}
+
+int mfx_trainer_bind_model(mfx_trainer *t, void *dP, void *dQ, void *dPG, void *dQG)
+{
+    if (!t || !dP || !dQ || !dPG || !dQG) return fail(MFX_E_ARG, "null pointer");
+    t->dP = (float *)dP;
+    t->dQ = (float *)dQ;
+    t->dPG = (float *)dPG;
+    t->dQG = (float *)dQG;
+    return MFX_OK;
+}
+
+static int ensure_model_storage(mfx_trainer *t)
+{
+    const mfx::Plan &p = t->plan;
+    if (!t->dP) {
+        HIP_TRY(t->oP.alloc((size_t)p.m * p.ka));
+        HIP_TRY(t->oQ.alloc((size_t)p.n * p.ka));
+        HIP_TRY(t->oPG.alloc((size_t)p.m * 2));
+        HIP_TRY(t->oQG.alloc((size_t)p.n * 2));
+        t->dP = t->oP.p;
+        t->dQ = t->oQ.p;
+        t->dPG = t->oPG.p;
+        t->dQG = t->oQG.p;
+    }
+    return MFX_OK;
+}
+
+int mfx_trainer_init_model(mfx_trainer *t, const int *omega_q_override)
+{
+    if (!t) return fail(MFX_E_ARG, "null trainer");
+    try {
+        HIP_TRY(hipSetDevice(t->device));
+        int rc = ensure_model_storage(t);
+        if (rc) return rc;
+        const mfx::Plan &p = t->plan;
+        std::vector<float> P, Q;
+        mfx::init_factors(p, omega_q_override, P, Q, env_int("MFX_HOST_THREADS", 0));
+        HIP_TRY(hipMemcpy(t->dP, P.data(), P.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t->dQ, Q.data(), Q.size() * 4, hipMemcpyHostToDevice));
+        if (omega_q_override)
+            HIP_TRY(hipMemcpy(t->dOmegaQ.p, omega_q_override, (size_t)p.n * 4, hipMemcpyHostToDevice));
+        // PG, QG <- 1 (reference mf/mf.cpp:2835)
+        HIP_TRY(mfx::launch_fill(t->dPG, 2LL * p.m, 1.0f, grid_for(2LL * p.m, t->cu_count), t->stream));
+        HIP_TRY(mfx::launch_fill(t->dQG, 2LL * p.n, 1.0f, grid_for(2LL * p.n, t->cu_count), t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        t->model_ready = true;
+        t->epochs_done = 0;
+        return MFX_OK;
+    } catch (const std::exception &e) {
+        return fail(MFX_E_NOMEM, e.what());
+    }
+}
+
+static hipEvent_t next_event(mfx_trainer *t)
+{
+    if (t->ev_used == t->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        t->ev_pool.push_back(e);
+    }
+    return t->ev_pool[t->ev_used++];
+}
+
+int mfx_trainer_epoch(mfx_trainer *t, int slow_only, void *stream_v)
+{
+    if (!t) return fail(MFX_E_ARG, "null trainer");
+    if (!t->model_ready) return fail(MFX_E_STATE, "model not initialised");
+    HIP_TRY(hipSetDevice(t->device));
+    hipStream_t s = stream_v ? (hipStream_t)stream_v : t->stream;
+    const mfx::Plan &p = t->plan;
+    const int ns = p.ns;
+    HIP_TRY(hipMemsetAsync(t->dSlotState.p, 0, (size_t)ns * ns * sizeof(int), s));
+    HIP_TRY(hipMemsetAsync(t->dScalars.p, 0, sizeof(double), s));
+
+    mfx::RoundArgs a;
+    a.own_rows = p.owner_is_q ? t->dQ : t->dP;
+    a.gat_rows = p.owner_is_q ? t->dP : t->dQ;
+    a.own_acc = p.owner_is_q ? t->dQG : t->dPG;
+    a.gat_acc = p.owner_is_q ? t->dPG : t->dQG;
+    a.entries = t->dEntries.p;
+    a.tasks = t->dTasks.p;
+    a.loss = t->dScalars.p;
+    a.lambda_own = p.owner_is_q ? t->lambda_q : t->lambda_p;
+    a.lambda_gat = p.owner_is_q ? t->lambda_p : t->lambda_q;
+    a.eta = t->opt.eta;
+    a.rk1 = t->rk1;
+    a.ka = p.ka;
+    a.slow_only = slow_only ? 1 : 0;
+    a.ns = ns;
+    a.n_xcc = t->xcd_count;
+    a.active_waves = t->waves_per_wg;
+    memcpy(a.xcc_rank, t->xcc_rank, sizeof(a.xcc_rank));
+    const int grid = t->xcd_count * t->wgs_per_xcd; // workgroups are dealt round-robin over XCDs
+    for (int i = 0; i < ns; ++i) {
+        const int r = (int)((i + t->epochs_done) % ns); // rotate the starting round per epoch
+        a.slot_task_ptr = t->dSlotPtr.p + (size_t)r * ns;
+        a.slot_cursor = t->dSlotState.p + (size_t)r * ns;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (t->timing) {
+            e0 = next_event(t);
+            e1 = next_event(t);
+            if (!e0 || !e1) return fail(MFX_E_HIP, "hipEventCreate failed");
+            HIP_TRY(hipEventRecord(e0, s));
+        }
+        HIP_TRY(mfx::launch_sgd_round(p.lanes, a, grid, s));
+        if (t->timing) HIP_TRY(hipEventRecord(e1, s));
+    }
+    t->epochs_done++;
+    t->loss_pending = true;
+    return MFX_OK;
+}
+
+// Every task of the last epoch must have been handed out: cursor >= task count per block.
+// Fails loudly if an XCD the probe saw received no workgroup in some launch.
+static int verify_rounds(mfx_trainer *t)
+{
+    if (!t->loss_pending) return MFX_OK;
+    const mfx::Plan &p = t->plan;
+    std::vector<int> cur((size_t)p.ns * p.ns);
+    HIP_TRY(hipMemcpy(cur.data(), t->dSlotState.p, cur.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < cur.size(); ++i)
+        if (cur[i] < p.slot_task_ptr[i + 1] - p.slot_task_ptr[i])
+            return fail(MFX_E_STATE, "a stripe block was left unprocessed: workgroup-to-XCD placement "
+                                     "differs from the probe (set MFX_STRIPES / rerun)");
+    t->loss_pending = false;
+    return MFX_OK;
+}
+
+int mfx_trainer_sync(mfx_trainer *t)
+{
+    if (!t) return fail(MFX_E_ARG, "null trainer");
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipDeviceSynchronize());
+    return verify_rounds(t);
+}
+
+int mfx_trainer_last_loss(mfx_trainer *t, double *sum_sq)
+{
+    if (!t || !sum_sq) return fail(MFX_E_ARG, "null pointer");
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&t->last_loss, t->dScalars.p, sizeof(double), hipMemcpyDeviceToHost));
+    *sum_sq = t->last_loss;
+    return verify_rounds(t);
+}
+
+int mfx_trainer_reg2(mfx_trainer *t, double *reg)
+{
+    if (!t || !reg) return fail(MFX_E_ARG, "null pointer");
+    if (!t->model_ready) return fail(MFX_E_STATE, "model not initialised");
+    HIP_TRY(hipSetDevice(t->device));
+    const mfx::Plan &p = t->plan;
+    double h[2] = {0, 0};
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(t->dScalars.p + 1, 0, 2 * sizeof(double)));
+    HIP_TRY(mfx::launch_reg2(t->dP, t->dOmegaP.p, p.m, p.ka, t->dScalars.p + 1,
+                             grid_for(p.m, t->cu_count), t->stream));
+    HIP_TRY(mfx::launch_reg2(t->dQ, t->dOmegaQ.p, p.n, p.ka, t->dScalars.p + 2,
+                             grid_for(p.n, t->cu_count), t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    HIP_TRY(hipMemcpy(h, t->dScalars.p + 1, 2 * sizeof(double), hipMemcpyDeviceToHost));
+    *reg = t->lambda_p * h[0] + t->lambda_q * h[1];
+    return MFX_OK;
+}
+
+int mfx_trainer_rmse(mfx_trainer *t, double *rmse)
+{
+    if (!t || !rmse) return fail(MFX_E_ARG, "null pointer");
+    if (!t->model_ready) return fail(MFX_E_STATE, "model not initialised");
+    HIP_TRY(hipSetDevice(t->device));
+    const mfx::Plan &p = t->plan;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(t->dScalars.p + 3, 0, sizeof(double)));
+    const float *own = p.owner_is_q ? t->dQ : t->dP, *gat = p.owner_is_q ? t->dP : t->dQ;
+    HIP_TRY(mfx::launch_sq_err_entries(p.lanes, own, gat, t->dEntries.p, t->n_entries, p.ka,
+                                       t->dScalars.p + 3, t->cu_count * 8, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    double s = 0;
+    HIP_TRY(hipMemcpy(&s, t->dScalars.p + 3, sizeof(double), hipMemcpyDeviceToHost));
+    *rmse = std::sqrt(s / (double)p.nnz) * (double)p.scale;
+    return MFX_OK;
+}
+
+int mfx_trainer_info(mfx_trainer *t, mfx_info *o)
+{
+    if (!t || !o) return fail(MFX_E_ARG, "null pointer");
+    const mfx::Plan &p = t->plan;
+    memset(o, 0, sizeof(*o));
+    o->m = p.m;
+    o->n = p.n;
+    o->k = p.k;
+    o->k_aligned = p.ka;
+    o->nnz = p.nnz;
+    o->avg = p.avg;
+    o->std_dev = p.std_dev;
+    o->scale = p.scale;
+    o->lambda_p_scaled = t->lambda_p;
+    o->lambda_q_scaled = t->lambda_q;
+    o->stripes = p.ns;
+    o->lanes_per_rating = p.lanes;
+    o->ratings_per_wave = p.groups;
+    o->owner_is_q = p.owner_is_q ? 1 : 0;
+    o->n_entries = t->n_entries;
+    o->n_tasks = t->n_tasks;
+    o->n_hot_rows = p.n_hot_rows;
+    o->cu_count = t->cu_count;
+    o->xcd_count = t->xcd_count;
+    o->wg_per_cu = t->wg_per_cu;
+    o->dP = t->dP;
+    o->dQ = t->dQ;
+    o->dPG = t->dPG;
+    o->dQG = t->dQG;
+    o->bytes_per_rating = 16.0 * p.ka + 44.0;
+    return MFX_OK;
+}
+
+int mfx_trainer_maps(mfx_trainer *t, int *p_map, int *q_map)
+{
+    if (!t) return fail(MFX_E_ARG, "null trainer");
+    if (p_map) memcpy(p_map, t->plan.p_map.data(), (size_t)t->plan.m * 4);
+    if (q_map) memcpy(q_map, t->plan.q_map.data(), (size_t)t->plan.n * 4);
+    return MFX_OK;
+}
+
+int mfx_trainer_get_model(mfx_trainer *t, float *P, float *Q, float *PG, float *QG)
+{
+    if (!t) return fail(MFX_E_ARG, "null trainer");
+    if (!t->model_ready) return fail(MFX_E_STATE, "model not initialised");
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const mfx::Plan &p = t->plan;
+    if (P) HIP_TRY(hipMemcpy(P, t->dP, (size_t)p.m * p.ka * 4, hipMemcpyDeviceToHost));
+    if (Q) HIP_TRY(hipMemcpy(Q, t->dQ, (size_t)p.n * p.ka * 4, hipMemcpyDeviceToHost));
+    if (PG) HIP_TRY(hipMemcpy(PG, t->dPG, (size_t)p.m * 8, hipMemcpyDeviceToHost));
+    if (QG) HIP_TRY(hipMemcpy(QG, t->dQG, (size_t)p.n * 8, hipMemcpyDeviceToHost));
+    return MFX_OK;
+}
+
+int mfx_trainer_set_model(mfx_trainer *t, const float *P, const float *Q, const float *PG,
+                          const float *QG)
+{
+    if (!t) return fail(MFX_E_ARG, "null trainer");
+    HIP_TRY(hipSetDevice(t->device));
+    int rc = ensure_model_storage(t);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    const mfx::Plan &p = t->plan;
+    if (P) HIP_TRY(hipMemcpy(t->dP, P, (size_t)p.m * p.ka * 4, hipMemcpyHostToDevice));
+    if (Q) HIP_TRY(hipMemcpy(t->dQ, Q, (size_t)p.n * p.ka * 4, hipMemcpyHostToDevice));
+    if (PG) HIP_TRY(hipMemcpy(t->dPG, PG, (size_t)p.m * 8, hipMemcpyHostToDevice));
+    if (QG) HIP_TRY(hipMemcpy(t->dQG, QG, (size_t)p.n * 8, hipMemcpyHostToDevice));
+    t->model_ready = true;
+    return MFX_OK;
+}
+
+int mfx_trainer_timing_enable(mfx_trainer *t, int on)
+{
+    if (!t) return fail(MFX_E_ARG, "null trainer");
+    t->timing = on != 0;
+    t->ev_used = 0;
+    return MFX_OK;
+}
+
+int mfx_trainer_timing_read(mfx_trainer *t, long long *launches, double *total_ms)
+{
+    if (!t || !launches || !total_ms) return fail(MFX_E_ARG, "null pointer");
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipDeviceSynchronize());
+    double tot = 0;
+    for (size_t i = 0; i + 1 < t->ev_used; i += 2) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, t->ev_pool[i], t->ev_pool[i + 1]));
+        tot += ms;
+    }
+    *launches = (long long)(t->ev_used / 2);
+    *total_ms = tot;
+    t->ev_used = 0;
+    return MFX_OK;
+}
+
+int mfx_trainer_export(mfx_trainer *t, float *arr, long long len)
+{
+    if (!t || !arr) return fail(MFX_E_ARG, "null pointer");
+    if (!t->model_ready) return fail(MFX_E_STATE, "model not initialised");
+    const mfx::Plan &p = t->plan;
+    const long long pn = (long long)p.m * p.k, qn = (long long)p.n * p.k;
+    if (len != pn + qn + 5) return fail(MFX_E_ARG, "model array length must be 5+(m+n)*k");
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipDeviceSynchronize());
+    DevBuf<float> tmp;
+    HIP_TRY(tmp.alloc((size_t)(pn + qn)));
+    const int do_scale = p.scale != 1.0f; // scale_model returns early on 1.0 (mf.cpp:531-532)
+    const float f = std::sqrt(p.scale);
+    HIP_TRY(mfx::launch_export(t->dP, t->dPmap.p, p.m, p.k, p.ka, f, do_scale, tmp.p,
+                               grid_for(pn, t->cu_count), t->stream));
+    HIP_TRY(mfx::launch_export(t->dQ, t->dQmap.p, p.n, p.k, p.ka, f, do_scale, tmp.p + pn,
+                               grid_for(qn, t->cu_count), t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    HIP_TRY(hipMemcpy(arr + 5, tmp.p, (size_t)(pn + qn) * 4, hipMemcpyDeviceToHost));
+    float b = p.avg / p.scale; // init_model's b (mf.cpp:3015), then scale_model (mf.cpp:536)
+    if (do_scale) b *= p.scale;
+    arr[0] = 0.0f; // P_L2_MFR
+    arr[1] = (float)p.m;
+    arr[2] = (float)p.n;
+    arr[3] = (float)p.k;
+    arr[4] = b;
+    return MFX_OK;
+}
+
+static int parse_header(const float *a, long long len, int &m, int &n, int &k, float &b)
+{
+    if (!a || len < 5) return fail(MFX_E_ARG, "model array too short");
+    m = (int)a[1]; // array_to_model, reference mf/mf.cpp:3455-3459
+    n = (int)a[2];
+    k = (int)a[3];
+    b = a[4];
+    if (m < 0 || n < 0 || k < 0 || len != (long long)m * k + (long long)n * k + 5)
+        return fail(MFX_E_ARG, "model array length does not match its header");
+    return MFX_OK;
+}
+
+int mfx_predict_array(const float *model_arr, long long model_len, const float *pairs,
+                      long long npairs, float *out)
+{
+    int m, n, k;
+    float b;
+    int rc = parse_header(model_arr, model_len, m, n, k, b);
+    if (rc) return rc;
+    if (npairs <= 0) return MFX_OK;
+    if (!pairs || !out) return fail(MFX_E_ARG, "null pointer");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(MFX_E_HIP, "no HIP device: the MI355X path cannot run (there is no CPU fallback)");
+    hipDeviceProp_t prop;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    DevBuf<float> dModel, dPairs, dOut;
+    HIP_TRY(dModel.alloc((size_t)model_len));
+    HIP_TRY(dPairs.alloc((size_t)npairs * 2));
+    HIP_TRY(dOut.alloc((size_t)npairs));
+    HIP_TRY(hipMemcpy(dModel.p, model_arr, (size_t)model_len * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dPairs.p, pairs, (size_t)npairs * 8, hipMemcpyHostToDevice));
+    HIP_TRY(mfx::launch_predict(dModel.p, m, n, k, b, dPairs.p, npairs, dOut.p,
+                                grid_for(npairs * 16, prop.multiProcessorCount), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dOut.p, (size_t)npairs * 4, hipMemcpyDeviceToHost));
+    return MFX_OK;
+}
+
+int mfx_rmse_array(const float *model_arr, long long model_len, const mfx_node *R, long long nnz,
+                   double *rmse)
+{
+    int m, n, k;
+    float b;
+    int rc = parse_header(model_arr, model_len, m, n, k, b);
+    if (rc) return rc;
+    if (!rmse) return fail(MFX_E_ARG, "null pointer");
+    if (nnz == 0) { // calc_rmse, reference mf/mf.cpp:4318-4319
+        *rmse = 0;
+        return MFX_OK;
+    }
+    if (!R) return fail(MFX_E_ARG, "null pointer");
+    hipDeviceProp_t prop;
+    int dev = 0, ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(MFX_E_HIP, "no HIP device: the MI355X path cannot run (there is no CPU fallback)");
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    DevBuf<float> dModel;
+    DevBuf<mfx::EntryD> dR;
+    DevBuf<double> dS;
+    HIP_TRY(dModel.alloc((size_t)model_len));
+    HIP_TRY(dR.alloc((size_t)nnz));
+    HIP_TRY(dS.alloc(1));
+    HIP_TRY(hipMemcpy(dModel.p, model_arr, (size_t)model_len * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dR.p, R, (size_t)nnz * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dS.p, 0, sizeof(double)));
+    HIP_TRY(mfx::launch_sq_err_nodes(dModel.p, m, n, k, b, dR.p, nnz, dS.p,
+                                     grid_for(nnz * 16, prop.multiProcessorCount), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    double s = 0;
+    HIP_TRY(hipMemcpy(&s, dS.p, sizeof(double), hipMemcpyDeviceToHost));
+    *rmse = std::sqrt(s / (double)nnz);
+    return MFX_OK;
+}
+
+struct mfx_hostplan {
+    mfx::Plan plan;
+};
+
+int mfx_hostplan_build(const mfx_node *R, long long nnz, int m, int n, const mfx_options *opt,
+                       mfx_hostplan **out)
+{
+    if (!out || !opt) return fail(MFX_E_ARG, "null pointer");
+    *out = nullptr;
+    if (int rc0 = check_options(*opt)) return rc0;
+    if (!R || nnz <= 0 || m <= 0 || n <= 0) return fail(MFX_E_EMPTY, "train on an empty training set");
+    mfx_hostplan *h = new (std::nothrow) mfx_hostplan();
+    if (!h) return fail(MFX_E_NOMEM, "out of host memory");
+    try {
+        const int stripes = opt->stripes > 0 ? opt->stripes : env_int("MFX_STRIPES", 8);
+        int wpw = 4;
+        int wgs = wgs_per_xcd_for(*opt, m, n, stripes, 32, &wpw);
+        mfx::build_plan((const mfx::Node *)R, nnz, m, n, plan_config(*opt, stripes, wgs, wpw), h->plan);
+    } catch (const std::bad_alloc &) {
+        delete h;
+        return fail(MFX_E_NOMEM, "out of host memory while building the plan");
+    } catch (const std::exception &e) {
+        delete h;
+        return fail(MFX_E_ARG, e.what());
+    }
+    *out = h;
+    return MFX_OK;
+}
+
+int mfx_hostplan_view(const mfx_hostplan *h, mfx_plan_view *v)
+{
+    if (!h || !v) return fail(MFX_E_ARG, "null pointer");
+    const mfx::Plan &p = h->plan;
+    memset(v, 0, sizeof(*v));
+    v->m = p.m;
+    v->n = p.n;
+    v->k = p.k;
+    v->k_aligned = p.ka;
+    v->stripes = p.ns;
+    v->lanes_per_rating = p.lanes;
+    v->ratings_per_wave = p.groups;
+    v->owner_is_q = p.owner_is_q;
+    v->nnz = p.nnz;
+    v->n_entries = (long long)p.entries.size();
+    v->n_tasks = (long long)p.tasks.size();
+    v->n_padding = p.n_padding;
+    v->n_hot_rows = p.n_hot_rows;
+    v->avg = p.avg;
+    v->std_dev = p.std_dev;
+    v->scale = p.scale;
+    v->inv_scale = p.inv_scale;
+    v->p_map = p.p_map.data();
+    v->q_map = p.q_map.data();
+    v->omega_p = p.omega_p.data();
+    v->omega_q = p.omega_q.data();
+    v->entries = p.entries.data();
+    v->tasks = p.tasks.data();
+    v->slot_task_ptr = p.slot_task_ptr.data();
+    return MFX_OK;
+}
+
+int mfx_hostplan_init_factors(const mfx_hostplan *h, float *P, float *Q)
+{
+    if (!h || !P || !Q) return fail(MFX_E_ARG, "null pointer");
+    try {
+        std::vector<float> vp, vq;
+        mfx::init_factors(h->plan, nullptr, vp, vq, env_int("MFX_HOST_THREADS", 0));
+        memcpy(P, vp.data(), vp.size() * sizeof(float));
+        memcpy(Q, vq.data(), vq.size() * sizeof(float));
+        return MFX_OK;
+    } catch (const std::exception &e) {
+        return fail(MFX_E_NOMEM, e.what());
+    }
+}
+
+void mfx_hostplan_destroy(mfx_hostplan *h) { delete h; }
+
+int mfx_synth_host(unsigned long long seed, unsigned long long shard, long long first,
+                   long long count, int m, int n, mfx_node *out)
+{
+    if (!out || count < 0 || m <= 0 || n <= 0) return fail(MFX_E_ARG, "bad argument");
+    mfx::parallel_ranges(count, 0, [&](long long b, long long e, int) {
+        for (long long i = b; i < e; ++i) {
+            mfx::SynthNode s = mfx::synth_rating(seed, shard, first + i, m, n);
+            out[i].u = s.u;
+            out[i].v = s.v;
+            out[i].r = s.r;
+        }
+    });
+    return MFX_OK;
+}
+
+int mfx_synth_device(unsigned long long seed, unsigned long long shard, long long first,
+                     long long count, int m, int n, void *out_dev, void *stream)
+{
+    if (!out_dev || count < 0 || m <= 0 || n <= 0) return fail(MFX_E_ARG, "bad argument");
+    if (count == 0) return MFX_OK;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    HIP_TRY(mfx::launch_synth(seed, shard, first, count, m, n, out_dev,
+                              grid_for(count, prop.multiProcessorCount), (hipStream_t)stream));
+    return MFX_OK;
+}
+
+} // extern "C"
+#pragma GCC visibility pop
