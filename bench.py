@@ -45,8 +45,10 @@ def cpu_baseline(pkg, w, budget_s=25.0):
         best = None
         t_start = time.time()
         for _ in range(3):
-            t1, _r = orc.ref_time_train(R, m, n, k, n1, threads, bins)
-            t2, rm = orc.ref_time_train(R, m, n, k, n2, threads, bins)
+            # each call runs in a killable child: the reference's shutdown race (quirk Q2)
+            # must never cost the bench line
+            t1, _r = orc.ref_time_train(R, m, n, k, n1, threads, bins, timeout=90)
+            t2, rm = orc.ref_time_train(R, m, n, k, n2, threads, bins, timeout=90)
             per_epoch = (t2 - t1) / (n2 - n1)
             if per_epoch > 0 and (best is None or per_epoch < best[0]):
                 best = (per_epoch, rm)
@@ -60,8 +62,8 @@ def cpu_baseline(pkg, w, budget_s=25.0):
         if time.time() - t_start < budget_s and cores > threads:
             th = min(cores, 64)
             bn = max(20, 2 * th + 1)
-            t1, _r = orc.ref_time_train(R, m, n, k, n1, th, bn)
-            t2, _r = orc.ref_time_train(R, m, n, k, n2, th, bn)
+            t1, _r = orc.ref_time_train(R, m, n, k, n1, th, bn, timeout=90)
+            t2, _r = orc.ref_time_train(R, m, n, k, n2, th, bn, timeout=90)
             if t2 > t1:
                 out["value_allcores"] = len(R) * (n2 - n1) / (t2 - t1)
                 out["allcores_threads"] = th

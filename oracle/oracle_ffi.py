@@ -216,26 +216,87 @@ def sgd_apply(P, Q, PG, QG, R, ka, lambda_p, lambda_q, eta, slow_only, rsqrt_mod
 
 
 # ---- the reference itself (development container only) --------------------------------------
+#
+# mf_train in the reference can hang at shutdown (quirk Q2, a timing race at any thread
+# count), and a ctypes call cannot be interrupted: the public helpers below run it in a child
+# process (oracle/ref_worker.py) with a timeout and retry.  The *_inproc forms are what the
+# child executes.
 
-def ref_train(R, m, n, k=8, iters=20, threads=1, bins=20, lambda_p=0.1, lambda_q=0.1, eta=0.1):
+def _ref_train_inproc(R, m, n, k, iters, threads, bins, lambda_p, lambda_q, eta):
     R = np.ascontiguousarray(R, dtype=NODE)
     lens = C.c_longlong()
     p = ref().ref_train_array(R.ctypes.data, len(R), m, n, k, threads, bins, iters, lambda_p, lambda_q, eta, C.byref(lens))
     if not p:
-        return None
+        raise RuntimeError("reference mf_train returned null")
     out = np.ctypeslib.as_array(p, (lens.value,)).copy()
     ref().ref_free(p)
     return out
 
 
-def ref_rmse(R, arr, m, n):
+def _ref_rmse_inproc(R, arr, m, n):
     R = np.ascontiguousarray(R, dtype=NODE)
     arr = np.ascontiguousarray(arr, dtype=np.float32)
     return ref().ref_rmse_array(R.ctypes.data, len(R), m, n, arr.ctypes.data)
 
 
-def ref_time_train(R, m, n, k, iters, threads, bins, lambda_p=0.1, lambda_q=0.1, eta=0.1):
+def _ref_time_inproc(R, m, n, k, iters, threads, bins, lambda_p, lambda_q, eta):
     R = np.ascontiguousarray(R, dtype=NODE)
     rm = C.c_double()
     secs = ref().ref_time_train(R.ctypes.data, len(R), m, n, k, threads, bins, iters, lambda_p, lambda_q, eta, C.byref(rm))
     return secs, rm.value
+
+
+class RefHang(RuntimeError):
+    """The reference did not return within the timeout on every attempt (quirk Q2)."""
+
+
+def ref_call(op, R, m, n, k, iters, threads, bins, lambda_p=0.1, lambda_q=0.1, eta=0.1,
+             timeout=None, attempts=4):
+    """Run one reference call in a killable child; returns the child's npz as a dict."""
+    import sys
+    import tempfile
+    R = np.ascontiguousarray(R, dtype=NODE)
+    if timeout is None:  # generous: ~1 us per rating-epoch-thread^-1 plus pre-processing
+        timeout = 30.0 + 3e-6 * len(R) * (iters + 4)
+    with tempfile.TemporaryDirectory(prefix="refcall_") as d:
+        inp, outp = os.path.join(d, "in.npz"), os.path.join(d, "out.npz")
+        np.savez(inp, op=np.array(op), R=R.view(np.uint8), cfg=np.array([m, n, k, iters, threads, bins]),
+                 hyper=np.array([lambda_p, lambda_q, eta], dtype=np.float64))
+        for attempt in range(attempts):
+            if os.path.exists(outp):
+                os.remove(outp)
+            child = subprocess.Popen([sys.executable, os.path.join(_HERE, "ref_worker.py"), inp, outp],
+                                     stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            try:
+                _, err = child.communicate(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                child.kill()  # exactly the process started above
+                child.communicate()
+                continue
+            if child.returncode == 0 and os.path.exists(outp):
+                with np.load(outp) as z:
+                    return {key: z[key] for key in z.files}
+            raise RuntimeError("reference worker failed: %s" % err.decode(errors="replace")[-2000:])
+    raise RefHang("reference %s did not return in %.0f s on %d attempts (shutdown race, quirk Q2)"
+                  % (op, timeout, attempts))
+
+
+def ref_train(R, m, n, k=8, iters=20, threads=1, bins=20, lambda_p=0.1, lambda_q=0.1, eta=0.1,
+              timeout=None):
+    return ref_call("train", R, m, n, k, iters, threads, bins, lambda_p, lambda_q, eta, timeout)["model"]
+
+
+def ref_train_rmse(R, m, n, k=8, iters=20, threads=1, bins=20, lambda_p=0.1, lambda_q=0.1, eta=0.1,
+                   timeout=None):
+    z = ref_call("train", R, m, n, k, iters, threads, bins, lambda_p, lambda_q, eta, timeout)
+    return z["model"], float(z["rmse"][0])
+
+
+def ref_rmse(R, arr, m, n):
+    """mf::calc_rmse of a model array (no training loop involved: safe in-process)."""
+    return _ref_rmse_inproc(R, arr, m, n)
+
+
+def ref_time_train(R, m, n, k, iters, threads, bins, lambda_p=0.1, lambda_q=0.1, eta=0.1, timeout=None):
+    z = ref_call("time", R, m, n, k, iters, threads, bins, lambda_p, lambda_q, eta, timeout)
+    return float(z["secs"][0]), float(z["rmse"][0])

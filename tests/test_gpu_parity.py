@@ -1,0 +1,179 @@
+"""GPU parity: the HIP path (through the C-ABI / the mf:: facade) against the oracle.
+
+Tolerances (floating point; the path is lock-free and its update order differs from the
+reference's, which is itself order-dependent -- SURVEY.md 3.4 Q2/Q3, 8d):
+  * one conflict-free pass of the kernel vs orc_sgd_one, same inputs:   1e-5 relative
+  * training, same triples / epochs / hyper-parameters: final training RMSE within
+    RMSE_RTOL = 2 % of the oracle's (3 % for problems under 1e5 ratings, where a stripe
+    holds only a few hundred rows)
+  * predictions / calc_rmse from the same model array:                   1e-5 relative
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RMSE_RTOL = 0.02
+
+
+def internal(R, t):
+    pm, qm = t.maps()
+    Ri = R.copy()
+    Ri["u"], Ri["v"] = pm[R["u"]], qm[R["v"]]
+    Ri["r"] = (R["r"] * (np.float32(1.0) / np.float32(t.info.scale))).astype(np.float32)
+    return Ri
+
+
+@pytest.mark.parametrize("k", [8, 16, 32, 40, 64, 128, 200])
+@pytest.mark.parametrize("slow", [True, False])
+def test_single_pass_matches_oracle_update(pkg, orc, k, slow):
+    """Every rating touches its own user and item: order cannot matter, so the kernel must
+    reproduce orc_sgd_one (mf.cpp:1222-1234, 1462-1548) rating by rating."""
+    m = n = 3000
+    rng = np.random.default_rng(k)
+    R = pkg.as_nodes(np.arange(m), rng.permutation(n), rng.uniform(1, 5, m).astype(np.float32))
+    t = pkg.Trainer(R, m, n, k=k)
+    t.init_model()
+    P, Q, PG, QG = t.get_model()
+    t.epoch(slow_only=slow); t.sync()
+    P1, Q1, PG1, QG1 = t.get_model()
+    i = t.info
+    loss = orc.sgd_apply(P, Q, PG, QG, internal(R, t), i.k_aligned, i.lambda_p_scaled, i.lambda_q_scaled, 0.1, slow)
+    for got, want in ((P1, P), (Q1, Q), (PG1, PG), (QG1, QG)):
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+    assert abs(t.last_loss() - loss) <= 1e-5 * loss
+    assert np.array_equal(P1[:, i.k:], np.zeros_like(P1[:, i.k:]))  # padding factors stay zero
+    t.close()
+
+
+def test_rk_fast_switch(pkg, orc):
+    """rk_mode=1 uses 1/(k_a-8) for slot 1 (the AVX/scalar builds, mf.cpp:1314-1315); default is the SSE build's 1/8."""
+    m = n = 1000; k = 32
+    R = pkg.as_nodes(np.arange(m), np.arange(n)[::-1].copy(), np.linspace(1, 5, m).astype(np.float32))
+    t = pkg.Trainer(R, m, n, k=k, rk_mode=1); t.init_model()
+    P, Q, PG, QG = t.get_model(); t.epoch(); t.sync(); P1, Q1, PG1, QG1 = t.get_model(); i = t.info
+    orc.sgd_apply(P, Q, PG, QG, internal(R, t), i.k_aligned, i.lambda_p_scaled, i.lambda_q_scaled, 0.1, False, rk_mode=orc.RK_FAST)
+    np.testing.assert_allclose(PG1, PG, rtol=1e-5); np.testing.assert_allclose(QG1, QG, rtol=1e-5)
+    t.close()
+
+
+TRAIN_CASES = [  # m, n, nnz, k, iters, tolerance
+    (2000, 1500, 120000, 16, 8, 0.03), (3000, 2000, 100000, 8, 8, 0.03), (3000, 2000, 100000, 40, 6, 0.03),
+    (20000, 10000, 2000000, 32, 10, RMSE_RTOL), (20000, 10000, 2000000, 64, 6, RMSE_RTOL),
+    (5000, 4000, 400000, 128, 5, RMSE_RTOL),
+]
+
+
+@pytest.mark.parametrize("m,n,nnz,k,iters,tol", TRAIN_CASES)
+def test_training_rmse_matches_oracle(pkg, orc, m, n, nnz, k, iters, tol):
+    R = pkg.synth_host(3, 0, nnz, m, n)
+    t = pkg.Trainer(R, m, n, k=k); t.init_model(); t.train(iters)
+    arr = t.export(); g_int = t.rmse(); t.close()
+    ref = orc.train(R, m, n, k=k, iters=iters)
+    want = orc.rmse(R, ref)
+    got = orc.rmse(R, arr)  # the checker scores the GPU's model with the reference formula
+    assert abs(got - want) / want < tol, (got, want)
+    assert abs(g_int - got) / got < 1e-4  # device-side RMSE agrees with calc_rmse on the exported array
+    assert arr[:4].tolist() == [0.0, m, n, k] and arr[4] == ref[4]  # fun, m, n, k, b
+    assert np.array_equal(np.isnan(arr), np.isnan(ref))
+
+
+def test_facade_toy_and_progress_table(pkg, orc, toy, capfd):
+    """mf::utility_train on mfTest.cpp's triples: header exact, factors / predictions near the reference's
+    (8 ratings in a different update order: compare fit, not bits)."""
+    arr = pkg.utility_train(toy["train"], 0.1, 0.1, 8, 30, 0.1)
+    table = capfd.readouterr().out.splitlines()
+    assert arr is not None and len(arr) == 5 + 3 * 8 + 4 * 8
+    assert arr[:5].tolist() == [0.0, 3.0, 4.0, 8.0, 4.75]
+    assert table[0].split() == ["iter", "tr_rmse", "obj"] and len(table) == 31 and table[30].split()[0] == "29"
+    assert abs(float(table[1].split()[1]) - 5.1111) < 0.05 and abs(float(table[30].split()[1]) - 0.2999) < 0.05
+    pred = pkg.utility_predict(toy["test"], arr)
+    t = toy["train"].reshape(-1, 3)
+    R = pkg.as_nodes(t[:, 0], t[:, 1], t[:, 2])
+    assert abs(orc.rmse(R, arr) - float(toy["rmse"])) < 0.03
+    np.testing.assert_allclose(pred[:8], toy["pred"][:8], atol=0.15)
+    assert pred[8] == pytest.approx(toy["pred"][8], abs=0.5)  # (2,2) is not in the training set
+
+
+@pytest.mark.parametrize("k", [8, 5, 33, 64])
+def test_predict_and_rmse_from_reference_model(pkg, orc, small, k):
+    """Batched mf_predict / calc_rmse on the device from a model the REFERENCE trained (golden fixture)."""
+    model, R = small["c_model"], small["c_R"]
+    m, n = int(model[1]), int(model[2])
+    rng = np.random.default_rng(1)
+    pairs = np.stack([rng.integers(-2, m + 3, 5000), rng.integers(-2, n + 3, 5000)], 1).astype(np.float32)
+    np.testing.assert_allclose(pkg.predict_array(model, pairs), orc.predict(model, pairs), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pkg.utility_predict(pairs, model), orc.utility_predict(pairs, model), rtol=1e-5, atol=1e-6)
+    assert abs(pkg.rmse_array(model, R) - float(small["c_rmse"][0])) < 1e-5
+    # other widths, NaN rows included
+    arr = orc.train(R[:3000], m, n, k=k, iters=2)
+    got, want = pkg.predict_array(arr, pairs), orc.predict(arr, pairs)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+    assert (got[(pairs[:, 0] < 0) | (pairs[:, 0] >= m)] == arr[4]).all()  # out of range -> b
+
+
+def test_edge_cases(pkg, orc):
+    # length mismatch: NULL instead of the reference's null dereference (mf.cpp:3463-3467, 3564)
+    arr = pkg.utility_train(np.array([0, 0, 5, 1, 1, 3, 0, 1, 4], dtype=np.float32), k=8, iters=3)
+    assert pkg.utility_predict(np.array([0, 0], dtype=np.float32), arr[:-1]) is None
+    assert len(pkg.utility_predict(np.zeros(0, dtype=np.float32), arr)) == 0  # empty request
+    # bad parameters / empty input: NULL, lens = 0 (check_parameter, mf.cpp:3115-3184)
+    assert pkg.utility_train(np.array([0, 0, 5], dtype=np.float32), k=0) is None
+    assert pkg.utility_train(np.array([0, 0, 5], dtype=np.float32), iters=0) is None
+    assert pkg.utility_train(np.array([0, 0, 5], dtype=np.float32), eta=-1.0) is None
+    assert pkg.utility_train(np.zeros(0, dtype=np.float32)) is None
+    assert pkg.utility_train(np.array([-1, 0, 5], dtype=np.float32)) is None
+    # unseen rows stay NaN and predict b; a single rating trains
+    one = pkg.utility_train(np.array([2, 3, 4.0], dtype=np.float32), k=8, iters=4)
+    assert one[:4].tolist() == [0, 3, 4, 8] and np.isnan(one[5:5 + 16]).all() and not np.isnan(one[5 + 16:5 + 24]).any()
+    assert pkg.utility_predict(np.array([0, 0, 2, 3], dtype=np.float32), one)[0] == one[4]
+    # k not a multiple of 8 / of 4
+    R = pkg.synth_host(2, 0, 50000, 1200, 900)
+    for k in (5, 12, 100):
+        t = pkg.Trainer(R, 1200, 900, k=k); t.init_model(); t.train(4); arr = t.export(); t.close()
+        want = orc.rmse(R, orc.train(R, 1200, 900, k=k, iters=4))
+        assert len(arr) == 5 + 2100 * k and abs(orc.rmse(R, arr) - want) / want < 0.03
+
+
+def test_determinism_of_everything_but_the_race(pkg):
+    """Pre-processing and initial factors are deterministic; two runs differ only through Hogwild ordering."""
+    R = pkg.synth_host(8, 0, 300000, 9000, 5000)
+    out = []
+    for _ in range(2):
+        t = pkg.Trainer(R, 9000, 5000, k=32); t.init_model()
+        P0 = t.get_model()[0].copy(); t.train(5); out.append((P0, t.rmse())); t.close()
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert abs(out[0][1] - out[1][1]) / out[0][1] < 5e-3
+
+
+def test_full_size_properties(pkg):
+    """BASELINE configs[1] (100k x 50k, 10M ratings, k=32) at full size: size-independent properties."""
+    m, n, nnz, k = 100000, 50000, 10000000, 32
+    R = pkg.synth_host(1, 0, nnz, m, n)
+    t = pkg.Trainer(R, m, n, k=k); t.init_model()
+    P0, Q0, PG0, QG0 = t.get_model()
+    assert (PG0 == 1).all() and (QG0 == 1).all()
+    losses = []
+    for it in range(12):
+        t.epoch(slow_only=(it == 0)); losses.append(t.last_loss())
+    P, Q, PG, QG = t.get_model()
+    i = t.info
+    tr = np.sqrt(np.array(losses) / nnz) * i.scale
+    assert (np.diff(tr) < 0).all()                       # the online training error falls every epoch
+    assert np.isfinite(P).all() and np.isfinite(Q).all()
+    assert (PG >= 1).all() and (QG >= 1).all()           # accumulators only grow (sums of squares)
+    assert (P0[:, 8:] == P[:, 8:]).mean() < 0.01          # all k factors move after epoch 0
+    rm = t.rmse()
+    assert 0.80 < rm < 0.87, rm                          # the oracle reaches 0.8363 after 12 epochs on these triples
+    arr = t.export()
+    assert abs(pkg.rmse_array(arr, R) - rm) / rm < 1e-4  # export (scale, shrink, un-permute) is consistent
+    t.close()
+
+
+def test_slow_only_epoch_touches_first_eight_factors(pkg):
+    R = pkg.synth_host(6, 0, 200000, 5000, 3000)
+    t = pkg.Trainer(R, 5000, 3000, k=32); t.init_model()
+    P0, Q0, PG0, QG0 = t.get_model(); t.epoch(slow_only=True); t.sync(); P1, Q1, PG1, QG1 = t.get_model()
+    assert np.array_equal(P0[:, 8:], P1[:, 8:]) and np.array_equal(Q0[:, 8:], Q1[:, 8:])
+    assert not np.array_equal(P0[:, :8], P1[:, :8])
+    assert (PG1[:, 1] == 1).all() and (QG1[:, 1] == 1).all() and (PG1[:, 0] > 1).any()
+    t.close()

@@ -1,0 +1,139 @@
+"""Host pre-processing of the product (plan.cpp via mfx_hostplan_*) against the oracle.
+
+Integer / index work: bit-exact.  Runs without a GPU.
+"""
+import numpy as np
+import pytest
+
+
+def internal(R, hp, orc):
+    Ri = R.copy()
+    Ri["u"], Ri["v"] = hp.p_map[R["u"]], hp.q_map[R["v"]]
+    Ri["r"] = (R["r"] * np.float32(hp.view.inv_scale)).astype(np.float32) if hp.view.inv_scale != 1.0 else R["r"]
+    return Ri
+
+
+@pytest.mark.parametrize("shape", [(3000, 2000, 90000, 32), (500, 4000, 30000, 8), (700, 650, 20000, 40)])
+def test_maps_stats_counts_init_match_oracle(pkg, orc, shape):
+    m, n, nnz, k = shape
+    R = pkg.synth_host(5, 0, nnz, m, n)
+    hp = pkg.HostPlan(R, m, n, k=k)
+    v = hp.view
+    # gen_random_map (mf.cpp:1009-1017)
+    assert np.array_equal(hp.p_map, orc.gen_random_map(m))
+    assert np.array_equal(hp.q_map, orc.gen_random_map(n))
+    # collect_info (mf.cpp:462-484), scale (mf.cpp:2999)
+    avg, sd = orc.collect_info(R)
+    assert (v.avg, v.std_dev) == (avg, sd)
+    assert v.scale == max(np.float32(1e-4), np.float32(sd))
+    assert v.k_aligned == orc.k_aligned(k)
+    # omega counts (grid_problem, mf.cpp:815-816) on relabelled ids
+    Ri = internal(R, hp, orc)
+    _, _, op, oq = orc.grid_problem(Ri, m, n, 20)
+    assert np.array_equal(hp.omega_p, op) and np.array_equal(hp.omega_q, oq)
+    # init_model (mf.cpp:952-1007): same minstd stream, NaN rows, zero padding
+    P0, Q0 = orc.init_model(m, n, k, op, oq)
+    P1, Q1 = hp.init_factors()
+    assert np.array_equal(P0.view(np.uint32), P1.view(np.uint32))
+    assert np.array_equal(Q0.view(np.uint32), Q1.view(np.uint32))
+
+
+def check_plan(pkg, orc, R, m, n, k, **kw):
+    hp = pkg.HostPlan(R, m, n, k=k, **kw)
+    v = hp.view
+    e, tasks, sptr = hp.entries, hp.tasks, hp.slot_task_ptr
+    NS, G = v.stripes, v.ratings_per_wave
+    assert G * v.lanes_per_rating == 64 and v.lanes_per_rating * 4 >= v.k_aligned
+    act = e["gat"] >= 0
+    assert act.sum() == len(R) and v.n_padding == len(e) - len(R)
+    # every rating exactly once, relabelled and scaled exactly as shuffle/scale_problem do
+    Ri = internal(R, hp, orc)
+    own = (e["own"][act] & 0x7FFFFFFF).astype(np.int64)
+    gat = e["gat"][act].astype(np.int64)
+    u, vv = (gat, own) if v.owner_is_q else (own, gat)
+    got = np.stack([u, vv, e["r"][act].view(np.uint32).astype(np.int64)], 1)
+    want = np.stack([Ri["u"].astype(np.int64), Ri["v"].astype(np.int64), Ri["r"].view(np.uint32).astype(np.int64)], 1)
+    assert np.array_equal(got[np.lexsort(got.T[::-1])], want[np.lexsort(want.T[::-1])])
+    # tasks tile the entry array; step-major, G entries per step
+    assert sptr[0] == 0 and sptr[-1] == len(tasks) and (np.diff(sptr) >= 0).all()
+    assert int((tasks["nsteps"].astype(np.int64) * G).sum()) == len(e)
+    assert np.array_equal(tasks["off"][1:], np.cumsum(tasks["nsteps"].astype(np.int64) * G)[:-1].astype(np.uint64))
+    n_own, n_gat = (n, m) if v.owner_is_q else (m, n)
+    seg_o, seg_g = -(-n_own // NS), -(-n_gat // NS)
+    own_all = (e["own"] & 0x7FFFFFFF).astype(np.int64)
+    for r in range(NS):
+        used_o, used_g = set(), set()
+        for s in range(NS):
+            t0, t1 = sptr[r * NS + s], sptr[r * NS + s + 1]
+            if t0 == t1:
+                continue
+            lo = int(tasks["off"][t0]); hi = int(tasks["off"][t1 - 1]) + int(tasks["nsteps"][t1 - 1]) * G
+            a = e["gat"][lo:hi] >= 0
+            so = set(np.unique(own_all[lo:hi][a] // seg_o)); sg = set(np.unique(e["gat"][lo:hi][a] // seg_g))
+            # a block lives in ONE owner stripe and ONE gathered stripe ...
+            assert so == {s} and sg == {(s + r) % NS}
+            # ... and the blocks of a round share no stripe (reference mf.cpp:133-141)
+            assert not (so & used_o) and not (sg & used_g)
+            used_o |= so; used_g |= sg
+    # inside every lane-group list: an owner change always carries the reload flag, and a list starts with one
+    for ti in range(len(tasks)):
+        off, ns = int(tasks["off"][ti]), int(tasks["nsteps"][ti])
+        blk = e[off: off + ns * G].reshape(ns, G)
+        for g in range(G):
+            col = blk[:, g]; a = col["gat"] >= 0
+            ids = (col["own"][a] & 0x7FFFFFFF); fl = (col["own"][a] >> 31).astype(bool)
+            if len(ids):
+                assert fl[0] and (fl[1:] | (ids[1:] == ids[:-1])).all()
+                assert not a[np.argmax(~a):].any() if (~a).any() else True  # padding only at the tail
+    return hp
+
+
+def test_plan_layout_invariants(pkg, orc):
+    R = pkg.synth_host(11, 0, 60000, 2500, 1800)
+    check_plan(pkg, orc, R, 2500, 1800, 32)
+    check_plan(pkg, orc, R, 2500, 1800, 8, stripes=4, task_steps=16)
+    check_plan(pkg, orc, R, 2500, 1800, 64, owner_side=1)
+
+
+def test_plan_edge_cases(pkg, orc):
+    # fewer rows than stripes, a single rating, a row that holds most of the ratings, duplicates
+    one = np.array([(0, 0, 3.5)], dtype=pkg.NODE)
+    hp = check_plan(pkg, orc, one, 1, 1, 8)
+    assert hp.view.scale == np.float32(1e-4)  # std 0 -> scale floor (mf.cpp:2999)
+    toy = np.array([(0, 0, 5), (0, 2, 10), (0, 3, 2), (1, 0, 7), (1, 1, 3), (1, 3, 0), (2, 1, 2), (2, 3, 9)], dtype=pkg.NODE)
+    check_plan(pkg, orc, toy, 3, 4, 8)
+    rng = np.random.default_rng(3)
+    hot = np.zeros(20000, dtype=pkg.NODE)
+    hot["u"] = rng.integers(0, 900, 20000); hot["v"] = np.where(rng.random(20000) < 0.6, 7, rng.integers(0, 300, 20000))
+    hot["r"] = rng.integers(1, 6, 20000)
+    hp = check_plan(pkg, orc, hot, 900, 300, 16)
+    assert hp.view.n_hot_rows > 0
+    # ragged: ids present only at the top of the range -> unseen rows, NaN init
+    sparse = np.array([(999, 499, 1.0), (0, 0, 5.0), (999, 0, 2.0)], dtype=pkg.NODE)
+    hp = check_plan(pkg, orc, sparse, 1000, 500, 8)
+    P, Q = hp.init_factors()
+    assert np.isnan(P[hp.omega_p == 0, :8]).all() and not np.isnan(P[hp.omega_p > 0]).any()
+
+
+def test_bad_arguments_fail_loudly(pkg):
+    R = np.array([(0, 0, 1.0)], dtype=pkg.NODE)
+    for kw in (dict(k=0), dict(k=8, eta=0.0), dict(k=8, lambda_p2=-1.0), dict(k=300)):
+        with pytest.raises(pkg.MfxError):
+            pkg.HostPlan(R, 1, 1, **kw)
+    with pytest.raises(pkg.MfxError):
+        pkg.HostPlan(np.array([(5, 0, 1.0)], dtype=pkg.NODE), 1, 1, k=8)  # id outside [0,m)
+    with pytest.raises(pkg.MfxError):
+        pkg.HostPlan(np.zeros(0, dtype=pkg.NODE), 1, 1, k=8)  # empty training set (mf.cpp:2792)
+
+
+def test_no_gpu_means_error_not_fallback(pkg):
+    """Without a device the product path must refuse, not compute on the CPU."""
+    if pkg.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    R = pkg.synth_host(1, 0, 1000, 50, 40)
+    with pytest.raises(pkg.MfxError, match="no HIP device"):
+        pkg.Trainer(R, 50, 40, k=8)
+    assert pkg.utility_train(np.array([0, 0, 5, 1, 1, 3], dtype=np.float32), k=8, iters=2) is None
+    arr = np.concatenate([[0, 1, 1, 8, 3.0], np.ones(16)]).astype(np.float32)
+    with pytest.raises(pkg.MfxError, match="no HIP device"):
+        pkg.predict_array(arr, [0, 0])
