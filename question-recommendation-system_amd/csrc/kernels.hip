@@ -69,8 +69,13 @@ __device__ __forceinline__ int aload(const int *p)
 }
 
 // factor loads: served by the XCD's L2, never by a stale per-CU L1 line
+#ifndef MFX_LD_PLAIN
 __device__ __forceinline__ f4 ld_row(const float *p) { return __builtin_nontemporal_load((const f4 *)p); }
 __device__ __forceinline__ f2 ld_acc(const float *p) { return __builtin_nontemporal_load((const f2 *)p); }
+#else // experiment only: L1-cached loads (can read a stale line)
+__device__ __forceinline__ f4 ld_row(const float *p) { return *(const f4 *)p; }
+__device__ __forceinline__ f2 ld_acc(const float *p) { return *(const f2 *)p; }
+#endif
 
 // ---- the SGD round ----------------------------------------------------------------------
 
@@ -131,79 +136,83 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     ogn = ld_acc(a.own_acc + (size_t)pf * 2);
                 }
                 for (int step = 0; step < nsteps; ++step) {
-                    EntryD e2 = pad;
-                    if (step + 2 < nsteps) e2 = ep[(size_t)(step + 2) * G];
+                    // ---- issue every load of this step, then one wait ----
+                    // (nothing that a load returns is touched after the stores at the bottom, so
+                    //  the next step's loads go out right behind them)
+                    const int s2 = step + 2 < nsteps ? step + 2 : nsteps - 1;
+                    EntryD e2 = ep[(size_t)s2 * G];
+                    if (step + 2 >= nsteps) e2.gat = -1;
                     const bool act = e.gat >= 0;
+                    const unsigned id = e.own & IDMASK;
                     float *grow = a.gat_rows + (size_t)(act ? e.gat : 0) * ka + d0;
                     float *gacc = a.gat_acc + (size_t)(act ? e.gat : 0) * 2;
                     f4 g = zero4;
-                    f2 gg = {1.0f, 1.0f};
-                    if (act) { // gathered row: issued first, everything below overlaps its latency
-                        if (lane_ok) g = ld_row(grow);
-                        gg = ld_acc(gacc);
-                        const unsigned id = e.own & IDMASK;
-                        if ((e.own >> 31) && id != cur) { // a new visit: switch the owner row
-                            if (cur != NONE) {
-                                if (lane_ok) *(f4 *)(a.own_rows + (size_t)cur * ka + d0) = o;
-                                if (lig == 0) *(f2 *)(a.own_acc + (size_t)cur * 2) = f2{og0, og1};
-                            }
-                            if (pf != id) { // not prefetched (cannot happen for lists built by plan.cpp)
-                                if (lane_ok) on = ld_row(a.own_rows + (size_t)id * ka + d0);
-                                ogn = ld_acc(a.own_acc + (size_t)id * 2);
-                            }
-                            o = on;
-                            og0 = ogn.x;
-                            og1 = ogn.y;
-                            cur = id;
+                    if (lane_ok) g = ld_row(grow);
+                    f2 gg = ld_acc(gacc);
+                    const bool newvisit = act && (e.own >> 31) && id != cur;
+                    if (newvisit) { // switch the owner row: write the old one back, take the prefetched one
+                        if (cur != NONE) {
+                            if (lane_ok) *(f4 *)(a.own_rows + (size_t)cur * ka + d0) = o;
+                            if (lig == 0) *(f2 *)(a.own_acc + (size_t)cur * 2) = f2{og0, og1};
                         }
+                        if (pf != id) { // not prefetched (cannot happen for lists built by plan.cpp)
+                            if (lane_ok) on = ld_row(a.own_rows + (size_t)id * ka + d0);
+                            ogn = ld_acc(a.own_acc + (size_t)id * 2);
+                        }
+                        o = on;
+                        og0 = ogn.x;
+                        og1 = ogn.y;
+                        cur = id;
                     }
                     // prefetch the owner row of the visit that starts at the next step
-                    if (e1.gat >= 0 && (e1.own >> 31)) {
-                        const unsigned id1 = e1.own & IDMASK;
-                        if (id1 != cur) {
-                            pf = id1;
-                            if (lane_ok) on = ld_row(a.own_rows + (size_t)id1 * ka + d0);
-                            ogn = ld_acc(a.own_acc + (size_t)id1 * 2);
-                        }
+                    const unsigned id1 = e1.own & IDMASK;
+                    if (e1.gat >= 0 && (e1.own >> 31) && id1 != cur) {
+                        pf = id1;
+                        if (lane_ok) on = ld_row(a.own_rows + (size_t)id1 * ka + d0);
+                        ogn = ld_acc(a.own_acc + (size_t)id1 * 2);
                     }
-                    if (act) {
-                        // z = p.q (calc_z), e = r - z (prepare_for_sg_update)
-                        float z = o.x * g.x + o.y * g.y + o.z * g.z + o.w * g.w;
-                        z = group_sum<LANES>(z);
-                        const float err = e.r - z;
-                        tsum += err * err;
-
-                        // sg_update: eta scaled by rsqrt of the slot this lane's dims belong to
-                        const float eta_o = eta * __builtin_amdgcn_rsqf(slot1 ? og1 : og0);
-                        const float eta_g = eta * __builtin_amdgcn_rsqf(slot1 ? gg.y : gg.x);
-                        float so = 0.0f, sg = 0.0f;
-                        if (upd) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float ov = o[j], gv = g[j];
-                                const float go = lam_o * ov - err * gv; // both use the OLD values
-                                const float gq = lam_g * gv - err * ov;
-                                so += go * go;
-                                sg += gq * gq;
-                                o[j] = ov - eta_o * go;
-                                g[j] = gv - eta_g * gq;
-                            }
-                        }
-                        const float so0 = group_sum<LANES>(slot1 ? 0.0f : so);
-                        const float sg0 = group_sum<LANES>(slot1 ? 0.0f : sg);
-                        og0 = og0 + so0 * rk0;
-                        gg.x = gg.x + sg0 * rk0;
-                        if (!SLOW) {
-                            const float so1 = group_sum<LANES>(slot1 ? so : 0.0f);
-                            const float sg1 = group_sum<LANES>(slot1 ? sg : 0.0f);
-                            og1 = og1 + so1 * rk1;
-                            gg.y = gg.y + sg1 * rk1;
-                        }
-                        if (lane_ok) *(f4 *)grow = g;
-                        if (lig == 0) *(f2 *)gacc = gg;
-                    }
-                    e = e1;
+                    const float rating = e.r;
+                    e = e1; // rotate the look-ahead here, before the stores
                     e1 = e2;
+
+                    // ---- compute: z = p.q (calc_z), err = r - z (prepare_for_sg_update) ----
+                    float z = o.x * g.x + o.y * g.y + o.z * g.z + o.w * g.w;
+                    z = group_sum<LANES>(z);
+                    const float err = act ? rating - z : 0.0f;
+                    tsum += err * err;
+
+                    // sg_update: eta scaled by rsqrt of the slot this lane's dims belong to
+                    const float eta_o = eta * __builtin_amdgcn_rsqf(slot1 ? og1 : og0);
+                    const float eta_g = eta * __builtin_amdgcn_rsqf(slot1 ? gg.y : gg.x);
+                    float so = 0.0f, sg = 0.0f;
+                    if (upd && act) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float ov = o[j], gv = g[j];
+                            const float go = lam_o * ov - err * gv; // both use the OLD values
+                            const float gq = lam_g * gv - err * ov;
+                            so += go * go;
+                            sg += gq * gq;
+                            o[j] = ov - eta_o * go;
+                            g[j] = gv - eta_g * gq;
+                        }
+                    }
+                    // the gathered row goes back first: the time between its load and this store
+                    // is the window in which another wave's update of the same row is lost
+                    if (act && lane_ok) *(f4 *)grow = g;
+                    const float sg0 = group_sum<LANES>(slot1 ? 0.0f : sg);
+                    gg.x = gg.x + sg0 * rk0;
+                    if (!SLOW) {
+                        const float sg1 = group_sum<LANES>(slot1 ? sg : 0.0f);
+                        gg.y = gg.y + sg1 * rk1;
+                    }
+                    if (act && lig == 0) *(f2 *)gacc = gg;
+                    const float so0 = group_sum<LANES>(slot1 ? 0.0f : so);
+                    og0 = og0 + so0 * rk0;
+                    if (!SLOW) {
+                        const float so1 = group_sum<LANES>(slot1 ? so : 0.0f);
+                        og1 = og1 + so1 * rk1;
+                    }
                 }
                 if (cur != NONE) {
                     if (lane_ok) *(f4 *)(a.own_rows + (size_t)cur * ka + d0) = o;

@@ -153,21 +153,21 @@ void pack_class(const Rat *rat, const std::vector<Visit> &visits, size_t vbeg, s
 }
 
 // Cut one (owner-stripe, gather-stripe) block into wavefront tasks.
-void pack_block(const Rat *rat, long long L, int G, int target, BlockOut &out)
+void pack_block(const Rat *rat, long long L, int G, int target, int hot_len, BlockOut &out)
 {
     if (L == 0) return;
-    // runs of equal owner id = visits; a run longer than two task lengths is cut into chains
-    // that may run in different lane groups (each works on its own copy of the owner row and
-    // the last one to finish wins -- measured to cost less RMSE than exchanging the row
-    // through memory every few ratings, DESIGN.md "Hot rows")
+    // runs of equal owner id = visits; a run longer than hot_len is cut into chains that may
+    // run in different lane groups (each works on its own copy of the owner row and the last
+    // one to finish wins -- measured to cost less RMSE than exchanging the row through
+    // memory every few ratings, DESIGN.md "Hot rows").  No list is longer than the longest
+    // visit, so hot_len also bounds the longest task of the launch.
     std::vector<Visit> visits;
-    const long long hot_len = 2LL * target;
     for (long long i = 0; i < L;) {
         long long j = i;
         while (j < L && rat[j].own == rat[i].own) ++j;
         long long len = j - i;
         if (len > hot_len) {
-            long long nch = (len + target - 1) / target;
+            long long nch = (len + hot_len - 1) / hot_len;
             long long per = (len + nch - 1) / nch;
             for (long long s = i; s < j; s += per)
                 visits.push_back({rat[i].own, (uint32_t)s, (uint32_t)std::min(per, j - s)});
@@ -195,7 +195,7 @@ void pack_block(const Rat *rat, long long L, int G, int target, BlockOut &out)
         } else {
             while (vend < visits.size() && acc < (long long)(frac[c] * (double)L)) acc += visits[vend++].len;
         }
-        pack_class(rat, visits, vbeg, vend, G, std::max(4, target >> c), out);
+        pack_class(rat, visits, vbeg, vend, G, std::max(8, target >> c), out);
         vbeg = vend;
     }
 }
@@ -279,6 +279,16 @@ void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cf
     // per-block sort by (owner, gathered) and task packing, blocks in parallel
     std::vector<BlockOut> outs(NB);
     const int G = p.groups;
+    // Full-size tasks hold about half of what one wave does in a launch (same T for every
+    // block: a block that is heavier than average must not get longer tasks, its XCD would
+    // finish the round last); the graded tail in pack_block keeps the end short.
+    int target = cfg.task_steps;
+    if (target <= 0) {
+        long long per_wave = nnz / ((long long)NB * G * std::max(1, cfg.waves_per_stripe));
+        target = (int)std::min<long long>(64, std::max<long long>(16, per_wave / 2));
+    }
+    const char *he = getenv("MFX_HOT_LEN"); // experiment knob
+    const int hot_len = he && *he ? std::max(8, atoi(he)) : std::max(64, target);
     {
         std::vector<int> blocks(NB);
         for (int b = 0; b < NB; ++b) blocks[b] = b;
@@ -297,14 +307,7 @@ void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cf
                 std::sort(beg, beg + L, [](const Rat &x, const Rat &y) {
                     return x.own != y.own ? x.own < y.own : x.gat < y.gat;
                 });
-                int target = cfg.task_steps;
-                if (target <= 0) {
-                    // about 1.5 full-size tasks per wave; the graded tail (pack_block) keeps
-                    // the end of the launch short
-                    long long t = 2 * L / ((long long)G * 3 * std::max(1, cfg.waves_per_stripe));
-                    target = (int)std::min<long long>(256, std::max<long long>(16, t));
-                }
-                pack_block(beg, L, G, target, outs[b]);
+                pack_block(beg, L, G, target, hot_len, outs[b]);
             }
         };
         int nt = std::min(threads, NB);

@@ -142,7 +142,7 @@ def test_determinism_of_everything_but_the_race(pkg):
         t = pkg.Trainer(R, 9000, 5000, k=32); t.init_model()
         P0 = t.get_model()[0].copy(); t.train(5); out.append((P0, t.rmse())); t.close()
     assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
-    assert abs(out[0][1] - out[1][1]) / out[0][1] < 5e-3
+    assert abs(out[0][1] - out[1][1]) / out[0][1] < RMSE_RTOL  # run-to-run spread stays inside the parity band
 
 
 def test_full_size_properties(pkg):
