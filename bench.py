@@ -33,6 +33,23 @@ WORKLOAD = dict(m=100000, n=50000, nnz=10000000, k=32, lambda_p=0.1, lambda_q=0.
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/r*_pmc_summary.txt; FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md, both in KiB).
+    bench.py cannot collect counters itself; None when no summary is present."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.txt")))
+    if not files:
+        return None
+    txt = open(files[-1]).read()
+    f = re.search(r"FETCH_SIZE:.*last half ([0-9.]+)", txt)
+    w = re.search(r"WRITE_SIZE:.*last half ([0-9.]+)", txt)
+    if not f or not w:
+        return None
+    return (2.0 * float(f.group(1)) + float(w.group(1))) * 1024.0
+
+
 def cpu_baseline(pkg, w, budget_s=25.0):
     """Reference CPU epoch rate on this host (iteration-delta)."""
     orc = ge.import_oracle()
@@ -84,6 +101,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nnz", type=int, default=WORKLOAD["nnz"], help=argparse.SUPPRESS)
+    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)  # "gloo": rehearsal of N>1 on one GPU
+    ap.add_argument("--same-device", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--combine", default=os.environ.get("MFX_COMBINE", "avg"),
+                    help="how replicas of Q are combined when N>1: avg (mean of replicas) | sum (sum of deltas) | "
+                         "hybrid (avg for the first epochs, then sum)")
+    ap.add_argument("--syncs-per-epoch", type=int, default=int(os.environ.get("MFX_SYNCS_PER_EPOCH", "1")),
+                    help="RCCL averaging points per epoch when N>1 (1..stripes)")
     args = ap.parse_args()
 
     import torch
@@ -96,11 +120,16 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no HIP device visible)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(args.backend)
 
     pkg = ge.import_package()
     w = dict(WORKLOAD)
@@ -127,11 +156,40 @@ def main():
     t.init_model()  # same seed stream on every rank: Q starts identical everywhere
     stream = torch.cuda.current_stream().cuda_stream
 
+    nsync = max(1, min(args.syncs_per_epoch, info.stripes)) if world > 1 else 1
+
+    state = {"epoch": 0}
+    Q0 = torch.empty_like(Q) if world > 1 and args.combine != "avg" else None
+    QG0 = torch.empty_like(QG) if Q0 is not None else None
+
+    def allreduce_sum(x):
+        if args.backend == "nccl":
+            dist.all_reduce(x, op=dist.ReduceOp.SUM)  # RCCL over xGMI
+        else:  # rehearsal path (gloo): stage through the host
+            h = x.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            x.copy_(h)
+
+    def combine_q():
+        """Replicated item factors after a local pass.  avg: Q <- mean_g Q_g.  sum: Q <- Q_sync + sum_g (Q_g - Q_sync),
+        i.e. every replica's updates are applied, as a sequential pass over all shards would."""
+        use_sum = args.combine == "sum" or (args.combine == "hybrid" and state["epoch"] >= 2)
+        if use_sum:
+            Q.sub_(Q0); QG.sub_(QG0)
+            allreduce_sum(Q); allreduce_sum(QG)
+            Q.add_(Q0); QG.add_(QG0)
+        else:
+            allreduce_sum(Q); allreduce_sum(QG)
+            Q.div_(world); QG.div_(world)
+
     def epoch(slow=False):
-        t.epoch(slow_only=slow, stream=stream)
-        if world > 1:  # replicated item factors: average over xGMI
-            dist.all_reduce(Q, op=dist.ReduceOp.AVG)
-            dist.all_reduce(QG, op=dist.ReduceOp.AVG)
+        for part in range(nsync):
+            if Q0 is not None:
+                Q0.copy_(Q); QG0.copy_(QG)
+            t.epoch_part(part, nsync, slow_only=slow, stream=stream)
+            if world > 1:
+                combine_q()
+        state["epoch"] += 1
 
     epoch(slow=True)  # the reference's epoch 0 (8 of k factors): not part of the metric
     for _ in range(args.warmup):
@@ -172,10 +230,13 @@ def main():
             "config": {"workload": "BASELINE configs[1]: synthetic %dx%d, %d ratings, k=%d per GPU "
                                    "(user-sharded; Q averaged over RCCL each epoch when N>1)" % (m, n, nnz, k),
                        "m_per_gpu": m, "n": n, "nnz_per_gpu": nnz, "k": k, "lambda": w["lambda_p"],
-                       "eta": w["eta"], "stripes": info.stripes, "wgs_per_launch": None},
+                       "eta": w["eta"], "stripes": info.stripes, "syncs_per_epoch": nsync,
+                       "combine": args.combine if world > 1 else None},
             "final_rmse": rmse, "epochs_trained": epochs_total,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
                          "kernel": "sgd_round<%d>" % info.lanes_per_rating,
                          "bytes_per_rating": info.bytes_per_rating,
                          "ratings_per_launch": nnz / info.stripes,

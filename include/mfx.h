@@ -96,6 +96,10 @@ int mfx_trainer_init_model(mfx_trainer *t, const int *omega_q_override);
  * the trainer's own stream).  slow_only = 1 reproduces epoch 0 (mf.cpp:2834, 1230-1231).
  * Asynchronous. */
 int mfx_trainer_epoch(mfx_trainer *t, int slow_only, void *stream);
+/* The same epoch in `nparts` pieces (rounds [part*stripes/nparts, (part+1)*stripes/nparts)), so a
+ * multi-GPU host can exchange the replicated factors more than once per epoch.  Call the parts in
+ * order 0..nparts-1. */
+int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream, int part, int nparts);
 int mfx_trainer_sync(mfx_trainer *t);
 
 /* Online sum of squared errors of the last finished epoch in scaled units

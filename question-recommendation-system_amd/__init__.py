@@ -85,6 +85,7 @@ def lib():
     L.mfx_trainer_bind_model.argtypes = [vp, vp, vp, vp, vp]
     L.mfx_trainer_init_model.argtypes = [vp, vp]
     L.mfx_trainer_epoch.argtypes = [vp, i32, vp]
+    L.mfx_trainer_epoch_part.argtypes = [vp, i32, vp, i32, i32]
     L.mfx_trainer_sync.argtypes = [vp]
     L.mfx_trainer_last_loss.argtypes = [vp, C.POINTER(C.c_double)]
     L.mfx_trainer_reg2.argtypes = [vp, C.POINTER(C.c_double)]
@@ -253,6 +254,9 @@ class Trainer:
 
     def epoch(self, slow_only=False, stream=None):
         _check(lib().mfx_trainer_epoch(self._h, 1 if slow_only else 0, stream))
+
+    def epoch_part(self, part, nparts, slow_only=False, stream=None):
+        _check(lib().mfx_trainer_epoch_part(self._h, 1 if slow_only else 0, stream, part, nparts))
 
     def sync(self):
         _check(lib().mfx_trainer_sync(self._h))

@@ -174,6 +174,12 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     const float rating = e.r;
                     e = e1; // rotate the look-ahead here, before the stores
                     e1 = e2;
+                    // One explicit settle point for every load of this step.  Without it hipcc
+                    // re-waits with vmcnt(0) at later uses of these registers, i.e. behind the
+                    // stores below, which costs a full store round trip per step.
+                    asm volatile("" : "+v"(g.x), "+v"(g.y), "+v"(g.z), "+v"(g.w), "+v"(gg.x), "+v"(gg.y));
+                    asm volatile("" : "+v"(on.x), "+v"(on.y), "+v"(on.z), "+v"(on.w), "+v"(ogn.x), "+v"(ogn.y));
+                    asm volatile("" : "+v"(e1.own), "+v"(e1.gat), "+v"(e1.r));
 
                     // ---- compute: z = p.q (calc_z), err = r - z (prepare_for_sg_update) ----
                     float z = o.x * g.x + o.y * g.y + o.z * g.z + o.w * g.w;

@@ -385,7 +385,7 @@ static hipEvent_t next_event(mfx_trainer *t)
     return t->ev_pool[t->ev_used++];
 }
 
-int mfx_trainer_epoch(mfx_trainer *t, int slow_only, void *stream_v)
+int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int part, int nparts)
 {
     if (!t) return fail(MFX_E_ARG, "null trainer");
     if (!t->model_ready) return fail(MFX_E_STATE, "model not initialised");
@@ -393,8 +393,12 @@ int mfx_trainer_epoch(mfx_trainer *t, int slow_only, void *stream_v)
     hipStream_t s = stream_v ? (hipStream_t)stream_v : t->stream;
     const mfx::Plan &p = t->plan;
     const int ns = p.ns;
-    HIP_TRY(hipMemsetAsync(t->dSlotState.p, 0, (size_t)ns * ns * sizeof(int), s));
-    HIP_TRY(hipMemsetAsync(t->dScalars.p, 0, sizeof(double), s));
+    if (nparts < 1 || nparts > ns || part < 0 || part >= nparts)
+        return fail(MFX_E_ARG, "epoch part out of range (1 <= nparts <= stripes)");
+    if (part == 0) {
+        HIP_TRY(hipMemsetAsync(t->dSlotState.p, 0, (size_t)ns * ns * sizeof(int), s));
+        HIP_TRY(hipMemsetAsync(t->dScalars.p, 0, sizeof(double), s));
+    }
 
     mfx::RoundArgs a;
     a.own_rows = p.owner_is_q ? t->dQ : t->dP;
@@ -415,7 +419,8 @@ int mfx_trainer_epoch(mfx_trainer *t, int slow_only, void *stream_v)
     a.active_waves = t->waves_per_wg;
     memcpy(a.xcc_rank, t->xcc_rank, sizeof(a.xcc_rank));
     const int grid = t->xcd_count * t->wgs_per_xcd; // workgroups are dealt round-robin over XCDs
-    for (int i = 0; i < ns; ++i) {
+    const int i_begin = (int)((long long)part * ns / nparts), i_end = (int)((long long)(part + 1) * ns / nparts);
+    for (int i = i_begin; i < i_end; ++i) {
         const int r = (int)((i + t->epochs_done) % ns); // rotate the starting round per epoch
         a.slot_task_ptr = t->dSlotPtr.p + (size_t)r * ns;
         a.slot_cursor = t->dSlotState.p + (size_t)r * ns;
@@ -429,9 +434,16 @@ int mfx_trainer_epoch(mfx_trainer *t, int slow_only, void *stream_v)
         HIP_TRY(mfx::launch_sgd_round(p.lanes, a, grid, s));
         if (t->timing) HIP_TRY(hipEventRecord(e1, s));
     }
-    t->epochs_done++;
-    t->loss_pending = true;
+    if (part == nparts - 1) {
+        t->epochs_done++;
+        t->loss_pending = true;
+    }
     return MFX_OK;
+}
+
+int mfx_trainer_epoch(mfx_trainer *t, int slow_only, void *stream_v)
+{
+    return mfx_trainer_epoch_part(t, slow_only, stream_v, 0, 1);
 }
 
 // Every task of the last epoch must have been handed out: cursor >= task count per block.
