@@ -7,9 +7,11 @@
 One "step" = one full-k SGD epoch (the per-rating loop of reference mf/mf.cpp:1201-1238 over
 every rating) on BASELINE.json configs[1]: synthetic 100k x 50k, 10 M ratings, k = 32, generated
 in HBM.  With N GPUs each rank trains its own 100k-user shard of an (N*100k) x 50k problem
-(weak scaling); the item factors Q and their Adagrad slots are replicated and averaged over
-RCCL after every epoch, inside the timed region.  Epoch 0 (slow_only, 8 of k factors) and the
-one-off pre-processing are outside the timed region, as in SURVEY.md 8(d).
+(weak scaling).  The item factors Q are shared over RCCL inside the timed region: by default item
+stripes of Q rotate round the ring of ranks (one writer per row, exact SGD -- multi.py); --combine avg
+selects BASELINE.json's replicate-and-average instead (measured to lose the fit).
+Epoch 0 (slow_only, 8 of k factors) and the one-off pre-processing are outside the timed region, as
+in SURVEY.md 8(d).
 
 Prints ONE JSON line (rank 0): metric/value/unit per the driver contract, plus
   roofline     -- algorithmic HBM bytes per launch / mean launch time (HIP events) vs 8 TB/s
@@ -103,9 +105,9 @@ def main():
     ap.add_argument("--nnz", type=int, default=WORKLOAD["nnz"], help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)  # "gloo": rehearsal of N>1 on one GPU
     ap.add_argument("--same-device", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--combine", default=os.environ.get("MFX_COMBINE", "avg"),
-                    help="how replicas of Q are combined when N>1: avg (mean of replicas) | sum (sum of deltas) | "
-                         "hybrid (avg for the first epochs, then sum)")
+    ap.add_argument("--combine", default=os.environ.get("MFX_COMBINE", "rotate"),
+                    help="how the item factors Q are shared when N>1: rotate (item stripes travel round the ring of "
+                         "ranks, one writer per row: exact SGD) | avg (replicas averaged by all-reduce) | sum | hybrid")
     ap.add_argument("--syncs-per-epoch", type=int, default=int(os.environ.get("MFX_SYNCS_PER_EPOCH", "1")),
                     help="RCCL averaging points per epoch when N>1 (1..stripes)")
     args = ap.parse_args()
@@ -141,55 +143,71 @@ def main():
     pkg.synth_device(w["seed"], 0, nnz, m, n, R_dev.data_ptr(), None, shard=rank)
     torch.cuda.synchronize()
 
-    opts = pkg.default_options(k=k, lambda_p2=w["lambda_p"], lambda_q2=w["lambda_q"], eta=w["eta"],
-                               device=local_rank)
-    t = pkg.Trainer(None, m, n, opts=opts, device_ptr=R_dev.data_ptr(), nnz=nnz)
-    del R_dev
-    info = t.info
-    ka = info.k_aligned
-    # factors live in torch tensors so RCCL can reduce them in place
-    P = torch.empty(m * ka, dtype=torch.float32, device=dev)
-    Q = torch.empty(n * ka, dtype=torch.float32, device=dev)
-    PG = torch.empty(m * 2, dtype=torch.float32, device=dev)
-    QG = torch.empty(n * 2, dtype=torch.float32, device=dev)
-    t.bind_model(P.data_ptr(), Q.data_ptr(), PG.data_ptr(), QG.data_ptr())
-    t.init_model()  # same seed stream on every rank: Q starts identical everywhere
-    stream = torch.cuda.current_stream().cuda_stream
+    rotate = world > 1 and args.combine == "rotate"
+    if rotate:
+        spec = __import__("importlib.util").util.spec_from_file_location("qrs_multi", os.path.join(ge.PKG_DIR, "multi.py"))
+        multi = __import__("importlib.util").util.module_from_spec(spec)
+        spec.loader.exec_module(multi)
+        R_host = R_dev.cpu().numpy().view(pkg.NODE).reshape(-1)  # plan building is host-side in this round
+        del R_dev
+        t = multi.RotatingTrainer(pkg, R_host, m, n, world, rank, dist, dev, backend=args.backend, k=k,
+                                  lambda_p2=w["lambda_p"], lambda_q2=w["lambda_q"], eta=w["eta"], device=local_rank)
+        del R_host
+        info = t.info
+        ka = info.k_aligned
+        stream = torch.cuda.current_stream().cuda_stream
+        nsync = world
 
-    nsync = max(1, min(args.syncs_per_epoch, info.stripes)) if world > 1 else 1
+        def epoch(slow=False):
+            t.epoch(slow_only=slow, stream=stream)
+    else:
+        opts = pkg.default_options(k=k, lambda_p2=w["lambda_p"], lambda_q2=w["lambda_q"], eta=w["eta"],
+                                   device=local_rank)
+        t = pkg.Trainer(None, m, n, opts=opts, device_ptr=R_dev.data_ptr(), nnz=nnz)
+        del R_dev
+        info = t.info
+        ka = info.k_aligned
+        # factors live in torch tensors so RCCL can reduce them in place
+        P = torch.empty(m * ka, dtype=torch.float32, device=dev)
+        Q = torch.empty(n * ka, dtype=torch.float32, device=dev)
+        PG = torch.empty(m * 2, dtype=torch.float32, device=dev)
+        QG = torch.empty(n * 2, dtype=torch.float32, device=dev)
+        t.bind_model(P.data_ptr(), Q.data_ptr(), PG.data_ptr(), QG.data_ptr())
+        t.init_model()  # same seed stream on every rank: Q starts identical everywhere
+        stream = torch.cuda.current_stream().cuda_stream
+        nsync = max(1, min(args.syncs_per_epoch, info.stripes)) if world > 1 else 1
+        state = {"epoch": 0}
+        Q0 = torch.empty_like(Q) if world > 1 and args.combine != "avg" else None
+        QG0 = torch.empty_like(QG) if Q0 is not None else None
 
-    state = {"epoch": 0}
-    Q0 = torch.empty_like(Q) if world > 1 and args.combine != "avg" else None
-    QG0 = torch.empty_like(QG) if Q0 is not None else None
+        def allreduce_sum(x):
+            if args.backend == "nccl":
+                dist.all_reduce(x, op=dist.ReduceOp.SUM)  # RCCL over xGMI
+            else:  # rehearsal path (gloo): stage through the host
+                h = x.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                x.copy_(h)
 
-    def allreduce_sum(x):
-        if args.backend == "nccl":
-            dist.all_reduce(x, op=dist.ReduceOp.SUM)  # RCCL over xGMI
-        else:  # rehearsal path (gloo): stage through the host
-            h = x.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM)
-            x.copy_(h)
+        def combine_q():
+            """Replicated item factors after a local pass.  avg: Q <- mean_g Q_g.  sum: Q <- Q_sync + sum_g (Q_g - Q_sync)
+            (diverges: kept only as a recorded experiment)."""
+            use_sum = args.combine == "sum" or (args.combine == "hybrid" and state["epoch"] >= 2)
+            if use_sum:
+                Q.sub_(Q0); QG.sub_(QG0)
+                allreduce_sum(Q); allreduce_sum(QG)
+                Q.add_(Q0); QG.add_(QG0)
+            else:
+                allreduce_sum(Q); allreduce_sum(QG)
+                Q.div_(world); QG.div_(world)
 
-    def combine_q():
-        """Replicated item factors after a local pass.  avg: Q <- mean_g Q_g.  sum: Q <- Q_sync + sum_g (Q_g - Q_sync),
-        i.e. every replica's updates are applied, as a sequential pass over all shards would."""
-        use_sum = args.combine == "sum" or (args.combine == "hybrid" and state["epoch"] >= 2)
-        if use_sum:
-            Q.sub_(Q0); QG.sub_(QG0)
-            allreduce_sum(Q); allreduce_sum(QG)
-            Q.add_(Q0); QG.add_(QG0)
-        else:
-            allreduce_sum(Q); allreduce_sum(QG)
-            Q.div_(world); QG.div_(world)
-
-    def epoch(slow=False):
-        for part in range(nsync):
-            if Q0 is not None:
-                Q0.copy_(Q); QG0.copy_(QG)
-            t.epoch_part(part, nsync, slow_only=slow, stream=stream)
-            if world > 1:
-                combine_q()
-        state["epoch"] += 1
+        def epoch(slow=False):
+            for part in range(nsync):
+                if Q0 is not None:
+                    Q0.copy_(Q); QG0.copy_(QG)
+                t.epoch_part(part, nsync, slow_only=slow, stream=stream)
+                if world > 1:
+                    combine_q()
+            state["epoch"] += 1
 
     epoch(slow=True)  # the reference's epoch 0 (8 of k factors): not part of the metric
     for _ in range(args.warmup):
@@ -219,7 +237,7 @@ def main():
 
     if rank == 0:
         value = world * nnz * args.steps / elapsed
-        bytes_per_launch = info.bytes_per_rating * nnz / info.stripes
+        bytes_per_launch = info.bytes_per_rating * nnz * args.steps / max(launches, 1)
         avg_launch_s = kern_ms / 1e3 / max(launches, 1)
         achieved = bytes_per_launch / avg_launch_s / 1e9
         out = {
@@ -228,7 +246,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic %dx%d, %d ratings, k=%d per GPU "
-                                   "(user-sharded; Q averaged over RCCL each epoch when N>1)" % (m, n, nnz, k),
+                                   "(N>1: users sharded over ranks, item stripes of Q rotate round the ranks over RCCL)" % (m, n, nnz, k),
                        "m_per_gpu": m, "n": n, "nnz_per_gpu": nnz, "k": k, "lambda": w["lambda_p"],
                        "eta": w["eta"], "stripes": info.stripes, "syncs_per_epoch": nsync,
                        "combine": args.combine if world > 1 else None},
@@ -239,7 +257,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "kernel": "sgd_round<%d>" % info.lanes_per_rating,
                          "bytes_per_rating": info.bytes_per_rating,
-                         "ratings_per_launch": nnz / info.stripes,
+                         "ratings_per_launch": nnz * args.steps / max(launches, 1),
                          "avg_launch_us": avg_launch_s * 1e6, "launches_timed": launches},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -49,7 +49,12 @@ typedef struct mfx_options {
                           mf.cpp:1233-1234); 1: 1/(k_a-8) for slot 1 (mf.cpp:1314-1315) */
     int owner_side;    /* 0 auto (side with fewer rows), 1 users (P), 2 items (Q)      */
     int identity_maps; /* 1: skip the id permutation (tests)                           */
-    int reserved[4];
+    int use_stats;     /* 1: take mean / std-dev from the next two fields instead of
+                          collect_info (mf.cpp:462-484) -- a problem split over several
+                          trainers or ranks must be scaled by ONE common figure        */
+    float stats_avg;
+    float stats_std;
+    int reserved[1];
 } mfx_options;
 
 typedef struct mfx_info {
@@ -88,9 +93,12 @@ void mfx_trainer_destroy(mfx_trainer *t);
 int mfx_trainer_bind_model(mfx_trainer *t, void *dP, void *dQ, void *dPG, void *dQG);
 
 /* init_model (mf.cpp:952-1007) + the accumulator fill (mf.cpp:2835), bit-identical to
- * the reference's stream.  omega_q_override (host, n ints, may be NULL) replaces the local
- * item counts when several ranks share Q. */
+ * the reference's stream.  omega_q_override (host, n ints in ORIGINAL item ids, may be NULL)
+ * replaces the local item counts when several ranks share Q. */
 int mfx_trainer_init_model(mfx_trainer *t, const int *omega_q_override);
+/* Same with both count vectors given (host, ORIGINAL ids, m resp. n ints, either may be NULL =
+ * local counts): rows with a zero count start as NaN, the others draw from the stream. */
+int mfx_trainer_init_model_counts(mfx_trainer *t, const int *omega_p, const int *omega_q);
 
 /* One SGD epoch = `stripes` kernel launches on `stream` (hipStream_t as void*, NULL =
  * the trainer's own stream).  slow_only = 1 reproduces epoch 0 (mf.cpp:2834, 1230-1231).
@@ -110,6 +118,8 @@ int mfx_trainer_reg2(mfx_trainer *t, double *reg);
 /* Training-set RMSE of the current factors in original rating units
  * (calc_rmse formula, mf.cpp:4316-4331).  Synchronises. */
 int mfx_trainer_rmse(mfx_trainer *t, double *rmse);
+/* The sum behind it, in original rating units squared (to pool several trainers / ranks). */
+int mfx_trainer_sq_err(mfx_trainer *t, double *sum_sq);
 
 int mfx_trainer_info(mfx_trainer *t, mfx_info *info);
 /* host copies of the id permutations (gen_random_map, mf.cpp:1009-1017): m and n ints */

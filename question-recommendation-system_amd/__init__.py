@@ -38,7 +38,8 @@ class Options(C.Structure):
                 ("eta", C.c_float), ("device", C.c_int), ("stripes", C.c_int),
                 ("wg_per_cu", C.c_int), ("task_steps", C.c_int), ("reserved0", C.c_int),
                 ("rk_mode", C.c_int), ("owner_side", C.c_int), ("identity_maps", C.c_int),
-                ("reserved", C.c_int * 4)]
+                ("use_stats", C.c_int), ("stats_avg", C.c_float), ("stats_std", C.c_float),
+                ("reserved", C.c_int * 1)]
 
 
 class Info(C.Structure):
@@ -84,6 +85,8 @@ def lib():
     L.mfx_trainer_destroy.restype = None
     L.mfx_trainer_bind_model.argtypes = [vp, vp, vp, vp, vp]
     L.mfx_trainer_init_model.argtypes = [vp, vp]
+    L.mfx_trainer_init_model_counts.argtypes = [vp, vp, vp]
+    L.mfx_trainer_sq_err.argtypes = [vp, C.POINTER(C.c_double)]
     L.mfx_trainer_epoch.argtypes = [vp, i32, vp]
     L.mfx_trainer_epoch_part.argtypes = [vp, i32, vp, i32, i32]
     L.mfx_trainer_sync.argtypes = [vp]
@@ -251,6 +254,19 @@ class Trainer:
             ptr = omega_q.ctypes.data
         _check(lib().mfx_trainer_init_model(self._h, ptr))
         self.info = self._info()
+
+    def init_model_counts(self, omega_p=None, omega_q=None):
+        """init_model with row counts given in ORIGINAL ids (None = this trainer's own)."""
+        a = None if omega_p is None else np.ascontiguousarray(omega_p, dtype=np.int32)
+        b = None if omega_q is None else np.ascontiguousarray(omega_q, dtype=np.int32)
+        _check(lib().mfx_trainer_init_model_counts(self._h, None if a is None else a.ctypes.data,
+                                                   None if b is None else b.ctypes.data))
+        self.info = self._info()
+
+    def sq_err(self):
+        v = C.c_double()
+        _check(lib().mfx_trainer_sq_err(self._h, C.byref(v)))
+        return v.value
 
     def epoch(self, slow_only=False, stream=None):
         _check(lib().mfx_trainer_epoch(self._h, 1 if slow_only else 0, stream))

@@ -219,7 +219,12 @@ void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cf
     p.groups = 64 / cfg.lanes;
     p.owner_is_q = cfg.owner_side == 0 ? (m >= n) : cfg.owner_side == 2;
 
-    collect_info(R, nnz, threads, p.avg, p.std_dev);
+    if (cfg.use_stats) {
+        p.avg = cfg.stats_avg;
+        p.std_dev = cfg.stats_std;
+    } else {
+        collect_info(R, nnz, threads, p.avg, p.std_dev);
+    }
     p.scale = std::max((float)1e-4, p.std_dev); // reference mf/mf.cpp:2999
     p.inv_scale = (float)1.0 / p.scale;         // reference mf/mf.cpp:3010
 
@@ -346,8 +351,8 @@ void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cf
         }
 }
 
-void init_factors(const Plan &p, const int *omega_q_override, std::vector<float> &P,
-                  std::vector<float> &Q, int threads)
+void init_factors(const Plan &p, const int *omega_p_override, const int *omega_q_override,
+                  std::vector<float> &P, std::vector<float> &Q, int threads)
 {
     // One minstd_rand0 stream, P rows then Q rows in internal order, k draws per seen row
     // scaled by sqrt(1/k); unseen rows NaN; padding zero (reference mf/mf.cpp:952-1007).
@@ -355,13 +360,14 @@ void init_factors(const Plan &p, const int *omega_q_override, std::vector<float>
     const float s = (float)std::sqrt(1.0 / k);
     P.assign((size_t)p.m * ka, 0.0f);
     Q.assign((size_t)p.n * ka, 0.0f);
+    const int *op = omega_p_override ? omega_p_override : p.omega_p.data();
     const int *oq = omega_q_override ? omega_q_override : p.omega_q.data();
     // stream position of every row = k * (seen rows before it)
     std::vector<uint64_t> pos((size_t)p.m + p.n);
     uint64_t seen = 0;
     for (int i = 0; i < p.m; ++i) {
         pos[i] = seen;
-        seen += p.omega_p[i] > 0;
+        seen += op[i] > 0;
     }
     for (int i = 0; i < p.n; ++i) {
         pos[(size_t)p.m + i] = seen;
@@ -374,7 +380,7 @@ void init_factors(const Plan &p, const int *omega_q_override, std::vector<float>
             bool isP = i < p.m;
             long long row = isP ? i : i - p.m;
             float *dst = (isP ? P.data() : Q.data()) + row * ka;
-            bool seen_row = isP ? p.omega_p[row] > 0 : oq[row] > 0;
+            bool seen_row = isP ? op[row] > 0 : oq[row] > 0;
             if (seen_row)
                 for (int d = 0; d < k; ++d) dst[d] = (float)(gen.unit() * s);
             else

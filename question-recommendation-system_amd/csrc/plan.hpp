@@ -32,6 +32,8 @@ struct PlanConfig {
     int task_steps = 0;       // 0 = auto
     int owner_side = 0;       // 0 auto, 1 users, 2 items
     bool identity_maps = false;
+    bool use_stats = false;   // take avg/std from below instead of collect_info
+    float stats_avg = 0, stats_std = 0;
     int waves_per_stripe = 256; // for auto task sizing
     int threads = 0;          // host worker threads, 0 = hardware_concurrency
 };
@@ -61,8 +63,9 @@ int lanes_for(int ka);
 void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cfg, Plan &out);
 
 // init_model (reference mf/mf.cpp:952-1007) in internal ids, padded stride ka.
-void init_factors(const Plan &plan, const int *omega_q_override, std::vector<float> &P,
-                  std::vector<float> &Q, int threads);
+// omega_*_override: counts in INTERNAL row order, or null for the plan's own.
+void init_factors(const Plan &plan, const int *omega_p_override, const int *omega_q_override,
+                  std::vector<float> &P, std::vector<float> &Q, int threads);
 
 void gen_random_map(int size, std::vector<int> &map); // reference mf/mf.cpp:1009-1017
 

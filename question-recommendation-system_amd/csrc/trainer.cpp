@@ -170,6 +170,9 @@ static mfx::PlanConfig plan_config(const mfx_options &opt, int stripes, int wgs_
     cfg.task_steps = opt.task_steps > 0 ? opt.task_steps : env_int("MFX_TASK_STEPS", 0);
     cfg.owner_side = opt.owner_side;
     cfg.identity_maps = opt.identity_maps != 0;
+    cfg.use_stats = opt.use_stats != 0;
+    cfg.stats_avg = opt.stats_avg;
+    cfg.stats_std = opt.stats_std;
     cfg.waves_per_stripe = wgs_per_xcd * waves_per_wg;
     cfg.threads = env_int("MFX_HOST_THREADS", 0);
     return cfg;
@@ -349,7 +352,7 @@ static int ensure_model_storage(mfx_trainer *t)
     return MFX_OK;
 }
 
-int mfx_trainer_init_model(mfx_trainer *t, const int *omega_q_override)
+int mfx_trainer_init_model_counts(mfx_trainer *t, const int *omega_p, const int *omega_q)
 {
     if (!t) return fail(MFX_E_ARG, "null trainer");
     try {
@@ -357,12 +360,23 @@ int mfx_trainer_init_model(mfx_trainer *t, const int *omega_q_override)
         int rc = ensure_model_storage(t);
         if (rc) return rc;
         const mfx::Plan &p = t->plan;
+        // overrides arrive in original ids; rows are stored in internal (permuted) order
+        std::vector<int> op, oq;
+        if (omega_p) {
+            op.resize(p.m);
+            for (int i = 0; i < p.m; ++i) op[p.p_map[i]] = omega_p[i];
+        }
+        if (omega_q) {
+            oq.resize(p.n);
+            for (int i = 0; i < p.n; ++i) oq[p.q_map[i]] = omega_q[i];
+        }
         std::vector<float> P, Q;
-        mfx::init_factors(p, omega_q_override, P, Q, env_int("MFX_HOST_THREADS", 0));
+        mfx::init_factors(p, omega_p ? op.data() : nullptr, omega_q ? oq.data() : nullptr, P, Q,
+                          env_int("MFX_HOST_THREADS", 0));
         HIP_TRY(hipMemcpy(t->dP, P.data(), P.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(t->dQ, Q.data(), Q.size() * 4, hipMemcpyHostToDevice));
-        if (omega_q_override)
-            HIP_TRY(hipMemcpy(t->dOmegaQ.p, omega_q_override, (size_t)p.n * 4, hipMemcpyHostToDevice));
+        if (omega_p) HIP_TRY(hipMemcpy(t->dOmegaP.p, op.data(), (size_t)p.m * 4, hipMemcpyHostToDevice));
+        if (omega_q) HIP_TRY(hipMemcpy(t->dOmegaQ.p, oq.data(), (size_t)p.n * 4, hipMemcpyHostToDevice));
         // PG, QG <- 1 (reference mf/mf.cpp:2835)
         HIP_TRY(mfx::launch_fill(t->dPG, 2LL * p.m, 1.0f, grid_for(2LL * p.m, t->cu_count), t->stream));
         HIP_TRY(mfx::launch_fill(t->dQG, 2LL * p.n, 1.0f, grid_for(2LL * p.n, t->cu_count), t->stream));
@@ -373,6 +387,11 @@ int mfx_trainer_init_model(mfx_trainer *t, const int *omega_q_override)
     } catch (const std::exception &e) {
         return fail(MFX_E_NOMEM, e.what());
     }
+}
+
+int mfx_trainer_init_model(mfx_trainer *t, const int *omega_q_override)
+{
+    return mfx_trainer_init_model_counts(t, nullptr, omega_q_override);
 }
 
 static hipEvent_t next_event(mfx_trainer *t)
@@ -502,6 +521,17 @@ int mfx_trainer_reg2(mfx_trainer *t, double *reg)
 int mfx_trainer_rmse(mfx_trainer *t, double *rmse)
 {
     if (!t || !rmse) return fail(MFX_E_ARG, "null pointer");
+    double s = 0;
+    int rc = mfx_trainer_sq_err(t, &s);
+    if (rc) return rc;
+    *rmse = std::sqrt(s / (double)t->plan.nnz);
+    return MFX_OK;
+}
+
+int mfx_trainer_sq_err(mfx_trainer *t, double *sum_sq)
+{
+    double *rmse = sum_sq;
+    if (!t || !rmse) return fail(MFX_E_ARG, "null pointer");
     if (!t->model_ready) return fail(MFX_E_STATE, "model not initialised");
     HIP_TRY(hipSetDevice(t->device));
     const mfx::Plan &p = t->plan;
@@ -513,7 +543,7 @@ int mfx_trainer_rmse(mfx_trainer *t, double *rmse)
     HIP_TRY(hipStreamSynchronize(t->stream));
     double s = 0;
     HIP_TRY(hipMemcpy(&s, t->dScalars.p + 3, sizeof(double), hipMemcpyDeviceToHost));
-    *rmse = std::sqrt(s / (double)p.nnz) * (double)p.scale;
+    *rmse = s * (double)p.scale * (double)p.scale;
     return MFX_OK;
 }
 
@@ -787,7 +817,7 @@ int mfx_hostplan_init_factors(const mfx_hostplan *h, float *P, float *Q)
     if (!h || !P || !Q) return fail(MFX_E_ARG, "null pointer");
     try {
         std::vector<float> vp, vq;
-        mfx::init_factors(h->plan, nullptr, vp, vq, env_int("MFX_HOST_THREADS", 0));
+        mfx::init_factors(h->plan, nullptr, nullptr, vp, vq, env_int("MFX_HOST_THREADS", 0));
         memcpy(P, vp.data(), vp.size() * sizeof(float));
         memcpy(Q, vq.data(), vq.size() * sizeof(float));
         return MFX_OK;
