@@ -239,6 +239,11 @@ def main():
         value = world * nnz * args.steps / elapsed
         bytes_per_launch = info.bytes_per_rating * nnz * args.steps / max(launches, 1)
         avg_launch_s = kern_ms / 1e3 / max(launches, 1)
+        timing_note = ("HIP events bracket each epoch's launches on the launch stream; mean = bracket / launches "
+                       "(inter-launch gaps included)")
+        if rotate:  # several trainers share the stream: use this rank's wall clock (stripe exchange included)
+            avg_launch_s = elapsed / max(launches, 1)
+            timing_note = "N>1: rank-0 wall time of the timed region / launches (ring shifts of Q included)"
         achieved = bytes_per_launch / avg_launch_s / 1e9
         out = {
             "metric": "ratings/sec per SGD epoch", "value": value, "unit": "ratings/s",
@@ -258,7 +263,7 @@ def main():
                          "kernel": "sgd_round<%d>" % info.lanes_per_rating,
                          "bytes_per_rating": info.bytes_per_rating,
                          "ratings_per_launch": nnz * args.steps / max(launches, 1),
-                         "avg_launch_us": avg_launch_s * 1e6, "launches_timed": launches},
+                         "avg_launch_us": avg_launch_s * 1e6, "launches_timed": launches, "timing": timing_note},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -228,10 +228,18 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
             }
         }
 
-    // online loss of this wave -> one double atomic (Scheduler::get_loss, mf.cpp:237-241)
+    // online loss (Scheduler::get_loss, mf.cpp:237-241): wave -> workgroup through LDS, then ONE
+    // double atomic per workgroup, spread over LOSS_SLOTS addresses (every wave adding to one
+    // word serialises ~1500 atomics at the end of a short launch)
+    __shared__ double wg_loss[4];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off);
-    if (lane == 0 && lsum != 0.0) atomicAdd(a.loss, lsum);
+    if (lane == 0) wg_loss[threadIdx.x >> 6] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double s = wg_loss[0] + wg_loss[1] + wg_loss[2] + wg_loss[3];
+        if (s != 0.0) atomicAdd(a.loss + (blockIdx.x % LOSS_SLOTS), s);
+    }
 }
 
 // Which XCC ids does a grid land on?  One bit per id seen (run once per trainer).

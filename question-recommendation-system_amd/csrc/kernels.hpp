@@ -9,6 +9,8 @@ namespace mfx {
 struct EntryD { uint32_t own; int32_t gat; float r; };
 struct TaskDescD { uint64_t off; uint32_t nsteps; uint32_t pad; };
 
+constexpr int LOSS_SLOTS = 256; // the epoch loss is kept as this many partial sums
+
 // Arguments of one SGD round (= one launch = NS stripe-disjoint blocks).
 struct RoundArgs {
     float *own_rows;  // factors of the owner side   (n_own x ka)
@@ -19,7 +21,7 @@ struct RoundArgs {
     const TaskDescD *tasks;
     const long long *slot_task_ptr; // ns+1 task offsets of this round
     int *slot_cursor;               // ns ints, zero before the launch
-    double *loss;                   // sum of e^2 (scaled units), accumulated
+    double *loss;                   // LOSS_SLOTS partial sums of e^2 (scaled units), accumulated
     float lambda_own, lambda_gat, eta, rk1;
     int ka, slow_only, ns;
     int n_xcc;                      // XCDs that take work

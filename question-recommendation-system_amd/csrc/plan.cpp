@@ -290,10 +290,12 @@ void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cf
     int target = cfg.task_steps;
     if (target <= 0) {
         long long per_wave = nnz / ((long long)NB * G * std::max(1, cfg.waves_per_stripe));
-        target = (int)std::min<long long>(64, std::max<long long>(16, per_wave / 2));
+        target = (int)std::min<long long>(64, std::max<long long>(8, per_wave / 2));
     }
     const char *he = getenv("MFX_HOT_LEN"); // experiment knob
-    const int hot_len = he && *he ? std::max(8, atoi(he)) : std::max(64, target);
+    // chains as long as two full tasks, at most 64 ratings (C2: 64); small launches (a stripe of a
+    // multi-GPU rotation) get shorter chains so that there are enough tasks for every wave
+    const int hot_len = he && *he ? std::max(8, atoi(he)) : std::min(64, std::max(16, 2 * target));
     {
         std::vector<int> blocks(NB);
         for (int b = 0; b < NB; ++b) blocks[b] = b;

@@ -15,8 +15,12 @@ for N in (1,2,4,8):
     st = torch.cuda.current_stream().cuda_stream
     t.epoch(slow_only=True, stream=st)
     for _ in range(3): t.epoch(stream=st)
-    torch.cuda.synchronize(); t.timing_enable(True); t0=time.time()
+    torch.cuda.synchronize(); t0=time.time()
+    for _ in range(10): t.epoch(stream=st)
+    torch.cuda.synchronize(); dt0=(time.time()-t0)/10
+    t.timing_enable(True); t0=time.time()
     for _ in range(10): t.epoch(stream=st)
     torch.cuda.synchronize(); dt=(time.time()-t0)/10; nl,ms=t.timing_read()
+    print("   without per-launch events: %.3f ms/epoch" % (dt0*1e3))
     print("N=%d: %.3f ms/epoch wall, kernels %.3f ms/epoch in %d launches (%.1f us each), tasks %s, rmse %.4f" % (N, dt*1e3, ms/10, nl//10, ms/nl*1e3, [x.info.n_tasks for x in t.trainers][:2], t.rmse()), flush=True)
     t.close()
