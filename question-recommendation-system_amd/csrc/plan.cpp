@@ -293,9 +293,13 @@ void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cf
         target = (int)std::min<long long>(64, std::max<long long>(8, per_wave / 2));
     }
     const char *he = getenv("MFX_HOT_LEN"); // experiment knob
-    // chains as long as two full tasks, at most 64 ratings (C2: 64); small launches (a stripe of a
-    // multi-GPU rotation) get shorter chains so that there are enough tasks for every wave
-    const int hot_len = he && *he ? std::max(8, atoi(he)) : std::min(64, std::max(16, 2 * target));
+    // A hot owner row is cut into chains of at most hot_len ratings.  Longer chains keep more of
+    // the row's updates (measured: 128 vs 64 is worth 2-3 % RMSE on small problems,
+    // profiles/experiments/r01_hot_chain_length.log), but a list must not outlast what one wave
+    // does in the launch, or it sets the launch time: hot_len = per-wave load, within [32,128].
+    const long long per_wave_load = nnz / ((long long)NB * G * std::max(1, cfg.waves_per_stripe));
+    const int hot_len = he && *he ? std::max(8, atoi(he))
+                                  : (int)std::min<long long>(128, std::max<long long>(32, per_wave_load));
     {
         std::vector<int> blocks(NB);
         for (int b = 0; b < NB; ++b) blocks[b] = b;

@@ -177,3 +177,57 @@ def test_slow_only_epoch_touches_first_eight_factors(pkg):
     assert not np.array_equal(P0[:, :8], P1[:, :8])
     assert (PG1[:, 1] == 1).all() and (QG1[:, 1] == 1).all() and (PG1[:, 0] > 1).any()
     t.close()
+
+
+def _load_multi():
+    import importlib.util
+    import os
+    import __graft_entry__ as ge
+    spec = importlib.util.spec_from_file_location("qrs_multi", os.path.join(ge.PKG_DIR, "multi.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_stripe_rotation_one_rank_is_plain_sgd(pkg, orc, world):
+    """The multi-GPU scheme (multi.RotatingTrainer) run by ONE rank without peers: N trainers over shared P,
+    item stripes of Q visited in turn.  Same ratings, same hyper-parameters, just another order of SGD:
+    final RMSE within the parity band of the oracle, and the factors stay consistent across trainers."""
+    import os
+    import torch
+    multi = _load_multi()
+    # isolate the rotation from the hot-row chain length (which follows the launch size and costs
+    # 2-3 % RMSE when short, DESIGN.md "Hot rows"): same chain bound as the single-trainer plan
+    os.environ["MFX_HOT_LEN"] = "128"
+    m, n, nnz, k, iters = 60000, 30000, 6000000, 32, 8
+    R = pkg.synth_host(3, 0, nnz, m, n)
+    t = multi.RotatingTrainer(pkg, R, m, n, world, 0, None, torch.device("cuda", 0), k=k)
+    assert sum(x.info.nnz for x in t.trainers) == nnz
+    assert len({(x.info.scale, x.info.avg) for x in t.trainers}) == 1  # ONE common scale (use_stats)
+    st = torch.cuda.current_stream().cuda_stream
+    for it in range(iters):
+        t.epoch(slow_only=(it == 0), stream=st)
+    got = t.rmse()
+    t.close()
+    os.environ.pop("MFX_HOT_LEN")
+    want = orc.rmse(R, orc.train(R, m, n, k=k, iters=iters))
+    assert abs(got - want) / want < 0.03, (got, want)
+
+
+def test_config2_full_size(pkg):
+    """BASELINE configs[2]: 1M x 500k, 100M ratings, k=64 (model 384 MB, beyond the L2s).  The oracle needs
+    260 s for 8 epochs of this; its result on these exact triples (seed 1) is recorded here:
+    RMSE 0.94767, tr_rmse per epoch 1.2245 1.0561 1.0375 1.0178 1.0004 0.9862 0.9752 0.9651."""
+    m, n, nnz, k = 1000000, 500000, 100000000, 64
+    R = pkg.synth_host(1, 0, nnz, m, n)
+    t = pkg.Trainer(R, m, n, k=k); t.init_model()
+    del R
+    tr = []
+    for it in range(8):
+        t.epoch(slow_only=(it == 0)); tr.append(np.sqrt(t.last_loss() / nnz) * t.info.scale)
+    rm = t.rmse()
+    t.close()
+    assert (np.diff(tr) < 0).all()
+    assert abs(tr[0] - 1.2245) / 1.2245 < 0.01          # epoch 0 starts from the same factors
+    assert abs(rm - 0.94767) / 0.94767 < 0.03, rm        # observed 0.925-0.928: the GPU path is slightly ahead
