@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--same-device", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--combine", default=os.environ.get("MFX_COMBINE", "rotate"),
                     help="how the item factors Q are shared when N>1: rotate (item stripes travel round the ring of "
-                         "ranks, one writer per row: exact SGD) | avg (replicas averaged by all-reduce) | sum | hybrid")
+                         "ranks, one writer per row: exact SGD) | avg (replicas averaged by all-reduce)")
     ap.add_argument("--syncs-per-epoch", type=int, default=int(os.environ.get("MFX_SYNCS_PER_EPOCH", "1")),
                     help="RCCL averaging points per epoch when N>1 (1..stripes)")
     args = ap.parse_args()
@@ -176,38 +176,23 @@ def main():
         t.init_model()  # same seed stream on every rank: Q starts identical everywhere
         stream = torch.cuda.current_stream().cuda_stream
         nsync = max(1, min(args.syncs_per_epoch, info.stripes)) if world > 1 else 1
-        state = {"epoch": 0}
-        Q0 = torch.empty_like(Q) if world > 1 and args.combine != "avg" else None
-        QG0 = torch.empty_like(QG) if Q0 is not None else None
 
-        def allreduce_sum(x):
-            if args.backend == "nccl":
-                dist.all_reduce(x, op=dist.ReduceOp.SUM)  # RCCL over xGMI
-            else:  # rehearsal path (gloo): stage through the host
-                h = x.cpu()
-                dist.all_reduce(h, op=dist.ReduceOp.SUM)
-                x.copy_(h)
-
-        def combine_q():
-            """Replicated item factors after a local pass.  avg: Q <- mean_g Q_g.  sum: Q <- Q_sync + sum_g (Q_g - Q_sync)
-            (diverges: kept only as a recorded experiment)."""
-            use_sum = args.combine == "sum" or (args.combine == "hybrid" and state["epoch"] >= 2)
-            if use_sum:
-                Q.sub_(Q0); QG.sub_(QG0)
-                allreduce_sum(Q); allreduce_sum(QG)
-                Q.add_(Q0); QG.add_(QG0)
-            else:
-                allreduce_sum(Q); allreduce_sum(QG)
-                Q.div_(world); QG.div_(world)
+        def average_q():
+            """--combine avg: replicated item factors, Q <- mean over ranks (summing the replicas' deltas
+            instead diverges -- profiles/experiments/r01_deltasum_4rank_rehearsal.log)."""
+            for x in (Q, QG):
+                if args.backend == "nccl":
+                    dist.all_reduce(x, op=dist.ReduceOp.AVG)  # RCCL over xGMI
+                else:  # rehearsal path (gloo): stage through the host
+                    h = x.cpu()
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                    x.copy_(h.div_(world))
 
         def epoch(slow=False):
             for part in range(nsync):
-                if Q0 is not None:
-                    Q0.copy_(Q); QG0.copy_(QG)
                 t.epoch_part(part, nsync, slow_only=slow, stream=stream)
                 if world > 1:
-                    combine_q()
-            state["epoch"] += 1
+                    average_q()
 
     epoch(slow=True)  # the reference's epoch 0 (8 of k factors): not part of the metric
     for _ in range(args.warmup):
