@@ -124,6 +124,8 @@ int mfx_trainer_sq_err(mfx_trainer *t, double *sum_sq);
 int mfx_trainer_info(mfx_trainer *t, mfx_info *info);
 /* host copies of the id permutations (gen_random_map, mf.cpp:1009-1017): m and n ints */
 int mfx_trainer_maps(mfx_trainer *t, int *p_map, int *q_map);
+/* the stripe/task layout as it sits in HBM (tests): n_entries*12 B, n_tasks*16 B, stripes^2+1 longs */
+int mfx_trainer_plan_copy(mfx_trainer *t, void *entries, void *tasks, long long *slot_task_ptr);
 /* raw factors in internal layout, for tests and checkpoints */
 int mfx_trainer_get_model(mfx_trainer *t, float *P, float *Q, float *PG, float *QG);
 int mfx_trainer_set_model(mfx_trainer *t, const float *P, const float *Q, const float *PG,

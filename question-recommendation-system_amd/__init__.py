@@ -96,6 +96,7 @@ def lib():
     L.mfx_trainer_info.argtypes = [vp, C.POINTER(Info)]
     L.mfx_trainer_maps.argtypes = [vp, vp, vp]
     L.mfx_trainer_get_model.argtypes = [vp, vp, vp, vp, vp]
+    L.mfx_trainer_plan_copy.argtypes = [vp, vp, vp, vp]
     L.mfx_trainer_set_model.argtypes = [vp, vp, vp, vp, vp]
     L.mfx_trainer_timing_enable.argtypes = [vp, i32]
     L.mfx_trainer_timing_read.argtypes = [vp, C.POINTER(ll), C.POINTER(C.c_double)]
@@ -297,6 +298,15 @@ class Trainer:
         q = np.empty(self.info.n, dtype=np.int32)
         _check(lib().mfx_trainer_maps(self._h, p.ctypes.data, q.ctypes.data))
         return p, q
+
+    def plan_copy(self):
+        """(entries, tasks, slot_task_ptr) of the layout resident in HBM."""
+        i = self.info
+        e = np.empty(i.n_entries, dtype=ENTRY)
+        t = np.empty(i.n_tasks, dtype=TASK)
+        sp = np.empty(i.stripes * i.stripes + 1, dtype=np.int64)
+        _check(lib().mfx_trainer_plan_copy(self._h, e.ctypes.data, t.ctypes.data, sp.ctypes.data))
+        return e, t, sp
 
     def get_model(self):
         i = self.info

@@ -88,18 +88,10 @@ namespace {
 
 struct Rat { uint32_t own; uint32_t gat; float r; };
 
-struct Visit { uint32_t own; uint32_t start; uint32_t len; };
-
-struct BlockOut {
-    std::vector<Entry> entries;
-    std::vector<TaskDesc> tasks; // offsets relative to this block
-    long long hot = 0, padding = 0;
-};
-
 // Pack one class of visits into tasks whose lane-group lists hold about `target` ratings:
 // longest-processing-time-first into G*ntasks lists, lists of similar load share a task.
-void pack_class(const Rat *rat, const std::vector<Visit> &visits, size_t vbeg, size_t vend, int G,
-                int target, BlockOut &out)
+void pack_class(const std::vector<Visit> &visits, size_t vbeg, size_t vend, int G, int target,
+                BlockPack &out)
 {
     if (vbeg >= vend) return;
     long long L = 0;
@@ -128,23 +120,18 @@ void pack_class(const Rat *rat, const std::vector<Visit> &visits, size_t vbeg, s
         uint32_t nsteps = load[order[t * G]];
         if (nsteps == 0) break; // the remaining lists are empty
         TaskDesc td;
-        td.off = out.entries.size();
+        td.off = out.n_entries;
         td.nsteps = nsteps;
         td.pad = 0;
-        size_t base = out.entries.size();
-        out.entries.resize(base + (size_t)nsteps * G, Entry{0u, -1, 0.0f});
+        const uint64_t base = out.n_entries;
+        out.n_entries += (uint64_t)nsteps * G;
         for (int g = 0; g < G; ++g) {
             uint32_t lst = order[t * G + g];
             uint32_t step = 0;
             for (uint32_t vi : list_visits[lst]) {
                 const Visit &v = visits[vi];
-                for (uint32_t x = 0; x < v.len; ++x, ++step) {
-                    const Rat &rr = rat[v.start + x];
-                    Entry &e = out.entries[base + (size_t)step * G + g];
-                    e.own = rr.own | (x == 0 ? 0x80000000u : 0u); // first rating of a visit
-                    e.gat = (int32_t)rr.gat;
-                    e.r = rr.r;
-                }
+                out.places.push_back({v.start, base + (uint64_t)step * G + g, v.len, 0u});
+                step += v.len;
             }
             out.padding += nsteps - step;
         }
@@ -152,30 +139,31 @@ void pack_class(const Rat *rat, const std::vector<Visit> &visits, size_t vbeg, s
     }
 }
 
-// Cut one (owner-stripe, gather-stripe) block into wavefront tasks.
-void pack_block(const Rat *rat, long long L, int G, int target, int hot_len, BlockOut &out)
+} // namespace
+
+// Cut one (owner-stripe, gather-stripe) block, given as its visits, into wavefront tasks.
+void pack_visits(std::vector<Visit> &raw, int G, int target, int hot_len, BlockPack &out)
 {
-    if (L == 0) return;
-    // runs of equal owner id = visits; a run longer than hot_len is cut into chains that may
-    // run in different lane groups (each works on its own copy of the owner row and the last
-    // one to finish wins -- measured to cost less RMSE than exchanging the row through
-    // memory every few ratings, DESIGN.md "Hot rows").  No list is longer than the longest
-    // visit, so hot_len also bounds the longest task of the launch.
+    if (raw.empty()) return;
+    // A visit (all ratings of one owner row in this block) longer than hot_len is cut into
+    // chains that may run in different lane groups (each works on its own copy of the owner row
+    // and the last one to finish wins -- measured to cost less RMSE than exchanging the row
+    // through memory every few ratings, DESIGN.md "Hot rows").  No list is longer than the
+    // longest visit, so hot_len also bounds the longest task of the launch.
     std::vector<Visit> visits;
-    for (long long i = 0; i < L;) {
-        long long j = i;
-        while (j < L && rat[j].own == rat[i].own) ++j;
-        long long len = j - i;
-        if (len > hot_len) {
-            long long nch = (len + hot_len - 1) / hot_len;
-            long long per = (len + nch - 1) / nch;
-            for (long long s = i; s < j; s += per)
-                visits.push_back({rat[i].own, (uint32_t)s, (uint32_t)std::min(per, j - s)});
+    visits.reserve(raw.size());
+    long long L = 0;
+    for (const Visit &v : raw) {
+        L += v.len;
+        if ((long long)v.len > hot_len) {
+            long long nch = ((long long)v.len + hot_len - 1) / hot_len;
+            long long per = ((long long)v.len + nch - 1) / nch;
+            for (long long s = 0; s < v.len; s += per)
+                visits.push_back({v.own, (uint32_t)std::min<long long>(per, v.len - s), v.start + (uint64_t)s});
             out.hot++;
         } else {
-            visits.push_back({rat[i].own, (uint32_t)i, (uint32_t)len});
+            visits.push_back(v);
         }
-        i = j;
     }
     std::stable_sort(visits.begin(), visits.end(),
                      [](const Visit &a, const Visit &b) { return a.len > b.len; });
@@ -195,20 +183,92 @@ void pack_block(const Rat *rat, long long L, int G, int target, int hot_len, Blo
         } else {
             while (vend < visits.size() && acc < (long long)(frac[c] * (double)L)) acc += visits[vend++].len;
         }
-        pack_class(rat, visits, vbeg, vend, G, std::max(8, target >> c), out);
+        pack_class(visits, vbeg, vend, G, std::max(8, target >> c), out);
         vbeg = vend;
     }
 }
 
-} // namespace
+void plan_sizes(long long nnz, int NB, int G, const PlanConfig &cfg, int &target, int &hot_len)
+{
+    // Full-size tasks hold about half of what one wave does in a launch (same T for every
+    // block: a block that is heavier than average must not get longer tasks, its XCD would
+    // finish the round last); the graded tail in pack_visits keeps the end short.
+    const long long per_wave = nnz / ((long long)NB * G * std::max(1, cfg.waves_per_stripe));
+    target = cfg.task_steps;
+    if (target <= 0) target = (int)std::min<long long>(64, std::max<long long>(8, per_wave / 2));
+    // A hot owner row is cut into chains of at most hot_len ratings.  Longer chains keep more of
+    // the row's updates (measured: 128 vs 64 is worth 2-3 % RMSE on small problems,
+    // profiles/experiments/r01_hot_chain_length.log), but a list must not outlast what one wave
+    // does in the launch, or it sets the launch time: hot_len = per-wave load, within [32,128].
+    const char *he = getenv("MFX_HOT_LEN"); // experiment knob
+    hot_len = he && *he ? std::max(8, atoi(he))
+                        : (int)std::min<long long>(128, std::max<long long>(32, per_wave));
+}
 
-void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cfg, Plan &p)
+void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig &cfg, Plan &p,
+                 std::vector<Placement> &places, int threads)
+{
+    const int NS = p.ns, NB = NS * NS, G = p.groups;
+    int target, hot_len;
+    plan_sizes(p.nnz, NB, G, cfg, target, hot_len);
+    std::vector<BlockPack> packs(NB);
+    {
+        std::vector<int> blocks(NB);
+        for (int b = 0; b < NB; ++b) blocks[b] = b;
+        std::sort(blocks.begin(), blocks.end(), [&](int a, int b) {
+            return block_visits[a].size() > block_visits[b].size();
+        });
+        std::atomic<int> next(0);
+        auto work = [&]() {
+            for (;;) {
+                int idx = next.fetch_add(1);
+                if (idx >= NB) break;
+                pack_visits(block_visits[blocks[idx]], G, target, hot_len, packs[blocks[idx]]);
+            }
+        };
+        std::vector<std::thread> pool;
+        int nt = std::max(1, std::min(threads, NB));
+        for (int t = 0; t < nt; ++t) pool.emplace_back(work);
+        for (auto &th : pool) th.join();
+    }
+    // concatenate in (round, slot) order: round r, slot s -> owner stripe s,
+    // gathered stripe (s + r) mod NS, so the NS slots of a round are stripe-disjoint
+    size_t tot_t = 0, tot_p = 0;
+    for (auto &o : packs) {
+        tot_t += o.tasks.size();
+        tot_p += o.places.size();
+        p.n_hot_rows += o.hot;
+        p.n_padding += o.padding;
+    }
+    p.tasks.clear();
+    p.tasks.reserve(tot_t);
+    places.clear();
+    places.reserve(tot_p);
+    p.slot_task_ptr.assign((size_t)NB + 1, 0);
+    uint64_t ebase = 0;
+    for (int r = 0; r < NS; ++r)
+        for (int s = 0; s < NS; ++s) {
+            BlockPack &o = packs[s * NS + (s + r) % NS];
+            for (TaskDesc td : o.tasks) {
+                td.off += ebase;
+                p.tasks.push_back(td);
+            }
+            for (Placement pl : o.places) {
+                pl.dst += ebase;
+                places.push_back(pl);
+            }
+            ebase += o.n_entries;
+            p.slot_task_ptr[(size_t)r * NS + s + 1] = (long long)p.tasks.size();
+            std::vector<TaskDesc>().swap(o.tasks);
+            std::vector<Placement>().swap(o.places);
+        }
+    p.n_entries = (long long)ebase;
+}
+
+void plan_header(long long nnz, int m, int n, const PlanConfig &cfg, Plan &p)
 {
     if (nnz <= 0 || m <= 0 || n <= 0) throw std::invalid_argument("empty problem");
     if (cfg.k < 1) throw std::invalid_argument("number of factors must be greater than zero");
-    int threads = cfg.threads > 0 ? cfg.threads : (int)std::thread::hardware_concurrency();
-    if (threads < 1) threads = 1;
-
     p.m = m;
     p.n = n;
     p.k = cfg.k;
@@ -218,6 +278,30 @@ void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cf
     p.lanes = cfg.lanes;
     p.groups = 64 / cfg.lanes;
     p.owner_is_q = cfg.owner_side == 0 ? (m >= n) : cfg.owner_side == 2;
+    if ((long long)p.ns * p.ns > 65535) throw std::invalid_argument("too many stripes");
+}
+
+void plan_stats_and_maps(const PlanConfig &cfg, Plan &p)
+{
+    p.scale = std::max((float)1e-4, p.std_dev); // reference mf/mf.cpp:2999
+    p.inv_scale = (float)1.0 / p.scale;         // reference mf/mf.cpp:3010
+    if (cfg.identity_maps) {
+        p.p_map.resize(p.m);
+        p.q_map.resize(p.n);
+        for (int i = 0; i < p.m; ++i) p.p_map[i] = i;
+        for (int i = 0; i < p.n; ++i) p.q_map[i] = i;
+    } else {
+        std::thread tq([&] { gen_random_map(p.n, p.q_map); });
+        gen_random_map(p.m, p.p_map);
+        tq.join();
+    }
+}
+
+void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cfg, Plan &p)
+{
+    plan_header(nnz, m, n, cfg, p);
+    int threads = cfg.threads > 0 ? cfg.threads : (int)std::thread::hardware_concurrency();
+    if (threads < 1) threads = 1;
 
     if (cfg.use_stats) {
         p.avg = cfg.stats_avg;
@@ -225,19 +309,7 @@ void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cf
     } else {
         collect_info(R, nnz, threads, p.avg, p.std_dev);
     }
-    p.scale = std::max((float)1e-4, p.std_dev); // reference mf/mf.cpp:2999
-    p.inv_scale = (float)1.0 / p.scale;         // reference mf/mf.cpp:3010
-
-    if (cfg.identity_maps) {
-        p.p_map.resize(m);
-        p.q_map.resize(n);
-        for (int i = 0; i < m; ++i) p.p_map[i] = i;
-        for (int i = 0; i < n; ++i) p.q_map[i] = i;
-    } else {
-        std::thread tq([&] { gen_random_map(n, p.q_map); });
-        gen_random_map(m, p.p_map);
-        tq.join();
-    }
+    plan_stats_and_maps(cfg, p);
 
     // validate ids, relabel (shuffle_problem, mf.cpp:775-791), scale (mf.cpp:517-527),
     // count rows (omega, mf.cpp:815-816) and bucket by block
@@ -265,7 +337,6 @@ void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cf
             blk[i] = (uint16_t)((x.own / seg_own) * NS + x.gat / seg_gat);
         }
     });
-    if (NB > 65535) throw std::invalid_argument("too many stripes");
     std::vector<long long> bptr(NB + 1, 0);
     for (long long i = 0; i < nnz; ++i) {
         bptr[blk[i] + 1]++;
@@ -281,80 +352,54 @@ void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cf
     std::vector<Rat>().swap(rat);
     std::vector<uint16_t>().swap(blk);
 
-    // per-block sort by (owner, gathered) and task packing, blocks in parallel
-    std::vector<BlockOut> outs(NB);
-    const int G = p.groups;
-    // Full-size tasks hold about half of what one wave does in a launch (same T for every
-    // block: a block that is heavier than average must not get longer tasks, its XCD would
-    // finish the round last); the graded tail in pack_block keeps the end short.
-    int target = cfg.task_steps;
-    if (target <= 0) {
-        long long per_wave = nnz / ((long long)NB * G * std::max(1, cfg.waves_per_stripe));
-        target = (int)std::min<long long>(64, std::max<long long>(8, per_wave / 2));
-    }
-    const char *he = getenv("MFX_HOT_LEN"); // experiment knob
-    // A hot owner row is cut into chains of at most hot_len ratings.  Longer chains keep more of
-    // the row's updates (measured: 128 vs 64 is worth 2-3 % RMSE on small problems,
-    // profiles/experiments/r01_hot_chain_length.log), but a list must not outlast what one wave
-    // does in the launch, or it sets the launch time: hot_len = per-wave load, within [32,128].
-    const long long per_wave_load = nnz / ((long long)NB * G * std::max(1, cfg.waves_per_stripe));
-    const int hot_len = he && *he ? std::max(8, atoi(he))
-                                  : (int)std::min<long long>(128, std::max<long long>(32, per_wave_load));
+    // per-block sort by (owner, gathered) -- stable, so equal pairs keep their input order, the
+    // same order the device path's radix sort leaves them in -- and the visit table
+    std::vector<std::vector<Visit>> block_visits(NB);
     {
-        std::vector<int> blocks(NB);
-        for (int b = 0; b < NB; ++b) blocks[b] = b;
-        std::sort(blocks.begin(), blocks.end(), [&](int a, int b) {
-            return bptr[a + 1] - bptr[a] > bptr[b + 1] - bptr[b];
-        });
-        std::vector<std::thread> pool;
         std::atomic<int> next(0);
         auto work = [&]() {
             for (;;) {
-                int idx = next.fetch_add(1);
-                if (idx >= NB) break;
-                int b = blocks[idx];
+                int b = next.fetch_add(1);
+                if (b >= NB) break;
                 Rat *beg = sorted.data() + bptr[b];
-                long long L = bptr[b + 1] - bptr[b];
-                std::sort(beg, beg + L, [](const Rat &x, const Rat &y) {
+                const long long L = bptr[b + 1] - bptr[b];
+                std::stable_sort(beg, beg + L, [](const Rat &x, const Rat &y) {
                     return x.own != y.own ? x.own < y.own : x.gat < y.gat;
                 });
-                pack_block(beg, L, G, target, hot_len, outs[b]);
+                std::vector<Visit> &vs = block_visits[b];
+                for (long long i = 0; i < L;) {
+                    long long j = i;
+                    while (j < L && beg[j].own == beg[i].own) ++j;
+                    vs.push_back({beg[i].own, (uint32_t)(j - i), (uint64_t)(bptr[b] + i)});
+                    i = j;
+                }
             }
         };
+        std::vector<std::thread> pool;
         int nt = std::min(threads, NB);
         for (int t = 0; t < nt; ++t) pool.emplace_back(work);
         for (auto &th : pool) th.join();
     }
-    std::vector<Rat>().swap(sorted);
 
-    // concatenate in (round, slot) order: round r, slot s -> owner stripe s,
-    // gathered stripe (s + r) mod NS, so the NS slots of a round are stripe-disjoint
-    size_t tot_e = 0, tot_t = 0;
-    for (auto &o : outs) {
-        tot_e += o.entries.size();
-        tot_t += o.tasks.size();
-        p.n_hot_rows += o.hot;
-        p.n_padding += o.padding;
-    }
-    p.entries.clear();
-    p.entries.reserve(tot_e);
-    p.tasks.clear();
-    p.tasks.reserve(tot_t);
-    p.slot_task_ptr.assign((size_t)NB + 1, 0);
-    for (int r = 0; r < NS; ++r)
-        for (int s = 0; s < NS; ++s) {
-            int b = s * NS + (s + r) % NS;
-            BlockOut &o = outs[b];
-            uint64_t ebase = p.entries.size();
-            p.entries.insert(p.entries.end(), o.entries.begin(), o.entries.end());
-            for (TaskDesc td : o.tasks) {
-                td.off += ebase;
-                p.tasks.push_back(td);
+    std::vector<Placement> places;
+    finish_plan(block_visits, cfg, p, places, threads);
+
+    // write the entries: a placement puts `len` consecutive sorted ratings into one lane-group
+    // list (stride G), the first one flagged "owner row changes here"
+    p.entries.assign((size_t)p.n_entries, Entry{0u, -1, 0.0f});
+    const int G = p.groups;
+    parallel_ranges((long long)places.size(), threads, [&](long long b, long long e, int) {
+        for (long long i = b; i < e; ++i) {
+            const Placement &pl = places[i];
+            for (uint32_t x = 0; x < pl.len; ++x) {
+                const Rat &rr = sorted[pl.src + x];
+                Entry &en = p.entries[pl.dst + (uint64_t)x * G];
+                en.own = rr.own | (x == 0 ? 0x80000000u : 0u);
+                en.gat = (int32_t)rr.gat;
+                en.r = rr.r;
             }
-            p.slot_task_ptr[(size_t)r * NS + s + 1] = (long long)p.tasks.size();
-            std::vector<Entry>().swap(o.entries);
-            std::vector<TaskDesc>().swap(o.tasks);
         }
+    });
 }
 
 void init_factors(const Plan &p, const int *omega_p_override, const int *omega_q_override,

@@ -25,6 +25,21 @@ static_assert(sizeof(Entry) == 12, "Entry must stay 12 bytes (mf_node sized)");
 // (entry index = off + step*G + group).
 struct TaskDesc { uint64_t off; uint32_t nsteps; uint32_t pad; };
 
+// All ratings of one owner row inside one block: `len` consecutive ratings of the block-sorted
+// rating array, starting at global index `start`.
+struct Visit { uint32_t own; uint32_t len; uint64_t start; };
+
+// "Put sorted ratings [src, src+len) into entries[dst + x*G], x = 0..len-1, the first one flagged."
+struct Placement { uint64_t src; uint64_t dst; uint32_t len; uint32_t pad; };
+
+// Result of packing one block; entry offsets are relative to the block.
+struct BlockPack {
+    std::vector<TaskDesc> tasks;
+    std::vector<Placement> places;
+    uint64_t n_entries = 0;
+    long long hot = 0, padding = 0;
+};
+
 struct PlanConfig {
     int k = 8;
     int stripes = 8;          // NS
@@ -49,9 +64,17 @@ struct Plan {
     std::vector<Entry> entries;
     std::vector<TaskDesc> tasks;
     std::vector<long long> slot_task_ptr; // ns*ns+1, ordered (round, slot)
+    long long n_entries = 0;   // entries.size() on the host path; on the device path the array lives in HBM only
     long long n_hot_rows = 0;
     long long n_padding = 0;
 };
+
+// pieces shared by the host builder (build_plan) and the device builder (prep.hip)
+void plan_header(long long nnz, int m, int n, const PlanConfig &cfg, Plan &p);
+void plan_stats_and_maps(const PlanConfig &cfg, Plan &p); // scale from std_dev, id permutations
+void pack_visits(std::vector<Visit> &visits, int G, int target, int hot_len, BlockPack &out);
+void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig &cfg, Plan &p,
+                 std::vector<Placement> &places, int threads);
 
 // number of floats per padded row: 8*ceil(k/8) (reference mf/mf.cpp:959)
 inline int k_aligned(int k) { return (k + 7) / 8 * 8; }

@@ -1,0 +1,267 @@
+// prep.hip -- pre-processing of a training problem on the device.
+//
+// GPU version of the reference's fpsg() prologue (reference mf/mf.cpp:2972-3016): collect_info
+// (462-484), shuffle_problem (775-791), scale_problem (517-527) and the bucketing + in-block
+// sort of grid_problem (793-858), for ratings that are already resident in HBM.  The result is
+// the same stripe/task layout plan.cpp builds on the host (tests compare the two entry for
+// entry); only the visit table (one record per owner row and block, ~nnz/25) crosses PCIe, the
+// packing of visits into tasks (plan.cpp: finish_plan) runs on the host, the entries are written
+// by a kernel.
+//
+//   ratings --key_build--> (block|own|gat) keys, scaled r, row counts
+//           --radix sort (hipCUB)--> block-major, owner-major order
+//           --run-length encode on (block|own)--> visit table --D2H--> finish_plan (host)
+//           --H2D placements--> emit_entries --> entries[] in HBM
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "kernels.hpp"
+#include "plan.hpp"
+#include "prep.hpp"
+
+namespace mfx {
+
+namespace {
+
+constexpr int ID_BITS = 24; // ids travel as floats through the facade: exact below 2^24
+
+struct HipErr : std::runtime_error {
+    explicit HipErr(const std::string &m) : std::runtime_error(m) {}
+};
+
+#define PREP_TRY(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) throw HipErr(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T> struct Buf {
+    T *p = nullptr;
+    void alloc(size_t n)
+    {
+        if (n == 0) n = 1;
+        PREP_TRY(hipMalloc((void **)&p, n * sizeof(T)));
+    }
+    ~Buf()
+    {
+        if (p) (void)hipFree(p);
+    }
+};
+
+// sum and sum of squares in double + id range check (collect_info, mf.cpp:462-484)
+__global__ __launch_bounds__(256) void stats_kernel(const Node *R, long long nnz, int m, int n,
+                                                    double *sums, int *bad)
+{
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nth = (long long)gridDim.x * blockDim.x;
+    double a = 0.0, q = 0.0;
+    int b = 0;
+    for (long long i = tid; i < nnz; i += nth) {
+        const Node x = R[i];
+        a += (double)x.r;
+        q += (double)x.r * x.r;
+        b |= (x.u < 0) | (x.u >= m) | (x.v < 0) | (x.v >= n);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off);
+        q += __shfl_down(q, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&sums[0], a);
+        atomicAdd(&sums[1], q);
+    }
+    if (b) atomicOr(bad, 1);
+}
+
+// relabel, scale, count rows, build the sort key (block | owner id | gathered id)
+__global__ __launch_bounds__(256) void key_build(const Node *R, long long nnz, const int *p_map,
+                                                 const int *q_map, int owner_is_q, float inv_scale,
+                                                 int do_scale, int seg_own, int seg_gat, int ns,
+                                                 int *omega_p, int *omega_q,
+                                                 unsigned long long *keys, float *vals)
+{
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nth = (long long)gridDim.x * blockDim.x;
+    for (long long i = tid; i < nnz; i += nth) {
+        const Node x = R[i];
+        const unsigned u = (unsigned)p_map[x.u], v = (unsigned)q_map[x.v];
+        atomicAdd(&omega_p[u], 1);
+        atomicAdd(&omega_q[v], 1);
+        const unsigned own = owner_is_q ? v : u, gat = owner_is_q ? u : v;
+        const unsigned long long blk = (unsigned long long)(own / (unsigned)seg_own) * ns + gat / (unsigned)seg_gat;
+        keys[i] = (blk << (2 * ID_BITS)) | ((unsigned long long)own << ID_BITS) | gat;
+        vals[i] = do_scale ? x.r * inv_scale : x.r;
+    }
+}
+
+struct VisitKey { // (block | owner) part of a sort key
+    __host__ __device__ unsigned long long operator()(unsigned long long k) const { return k >> ID_BITS; }
+};
+
+__global__ __launch_bounds__(256) void fill_entries(EntryD *e, long long n)
+{
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nth = (long long)gridDim.x * blockDim.x;
+    for (long long i = tid; i < n; i += nth) e[i] = EntryD{0u, -1, 0.0f};
+}
+
+// one lane per placement chunk: entries[dst + x*G] <- sorted rating src+x
+__global__ __launch_bounds__(256) void emit_entries(const Placement *pl, long long npl,
+                                                    const unsigned long long *keys, const float *vals,
+                                                    int G, EntryD *entries)
+{
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nth = (long long)gridDim.x * blockDim.x;
+    for (long long i = tid; i < npl; i += nth) {
+        const Placement p = pl[i];
+        for (unsigned x = 0; x < p.len; ++x) {
+            const unsigned long long k = keys[p.src + x];
+            EntryD e;
+            e.own = (unsigned)((k >> ID_BITS) & ((1u << ID_BITS) - 1)) | (x == 0 ? 0x80000000u : 0u);
+            e.gat = (int)(k & ((1u << ID_BITS) - 1));
+            e.r = vals[p.src + x];
+            entries[p.dst + (unsigned long long)x * G] = e;
+        }
+    }
+}
+
+int grid_of(long long n, int cu) { return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)cu * 8)); }
+
+} // namespace
+
+bool device_prep_supported(int m, int n) { return m <= (1 << ID_BITS) && n <= (1 << ID_BITS); }
+
+void build_plan_device(const void *dR_v, long long nnz, int m, int n, const PlanConfig &cfg, int cu_count,
+                       hipStream_t s, Plan &p, EntryD **d_entries_out)
+{
+    const Node *dR = (const Node *)dR_v;
+    *d_entries_out = nullptr;
+    plan_header(nnz, m, n, cfg, p);
+    if (!device_prep_supported(m, n)) throw std::invalid_argument("ids beyond 2^24 need the host plan builder");
+    int threads = cfg.threads > 0 ? cfg.threads : (int)std::thread::hardware_concurrency();
+    if (threads < 1) threads = 1;
+    const int NS = p.ns, NB = NS * NS, G = p.groups;
+
+    // 1. statistics + id validation
+    Buf<double> dSums;
+    Buf<int> dBad;
+    dSums.alloc(2);
+    dBad.alloc(1);
+    PREP_TRY(hipMemsetAsync(dSums.p, 0, 2 * sizeof(double), s));
+    PREP_TRY(hipMemsetAsync(dBad.p, 0, sizeof(int), s));
+    hipLaunchKernelGGL(stats_kernel, dim3(grid_of(nnz, cu_count)), dim3(256), 0, s, dR, nnz, m, n, dSums.p, dBad.p);
+    double sums[2];
+    int bad = 0;
+    PREP_TRY(hipMemcpyAsync(sums, dSums.p, sizeof(sums), hipMemcpyDeviceToHost, s));
+    PREP_TRY(hipMemcpyAsync(&bad, dBad.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    PREP_TRY(hipStreamSynchronize(s));
+    if (bad) throw std::invalid_argument("rating with id outside [0,m) x [0,n)");
+    if (cfg.use_stats) {
+        p.avg = cfg.stats_avg;
+        p.std_dev = cfg.stats_std;
+    } else {
+        const double ex = sums[0] / (double)nnz, ex2 = sums[1] / (double)nnz;
+        p.avg = (float)ex;
+        p.std_dev = (float)std::sqrt(ex2 - ex * ex);
+    }
+    plan_stats_and_maps(cfg, p); // scale, inv_scale, p_map, q_map (host: the glibc-compatible shuffle is serial)
+
+    // 2. keys
+    Buf<int> dPmap, dQmap, dOmegaP, dOmegaQ;
+    dPmap.alloc(m);
+    dQmap.alloc(n);
+    dOmegaP.alloc(m);
+    dOmegaQ.alloc(n);
+    PREP_TRY(hipMemcpyAsync(dPmap.p, p.p_map.data(), (size_t)m * 4, hipMemcpyHostToDevice, s));
+    PREP_TRY(hipMemcpyAsync(dQmap.p, p.q_map.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    PREP_TRY(hipMemsetAsync(dOmegaP.p, 0, (size_t)m * 4, s));
+    PREP_TRY(hipMemsetAsync(dOmegaQ.p, 0, (size_t)n * 4, s));
+    Buf<unsigned long long> dKeyA, dKeyB;
+    Buf<float> dValA, dValB;
+    dKeyA.alloc(nnz);
+    dKeyB.alloc(nnz);
+    dValA.alloc(nnz);
+    dValB.alloc(nnz);
+    const int n_own = p.owner_is_q ? n : m, n_gat = p.owner_is_q ? m : n;
+    const int seg_own = (n_own + NS - 1) / NS, seg_gat = (n_gat + NS - 1) / NS;
+    hipLaunchKernelGGL(key_build, dim3(grid_of(nnz, cu_count)), dim3(256), 0, s, dR, nnz, dPmap.p, dQmap.p,
+                       p.owner_is_q ? 1 : 0, p.inv_scale, p.inv_scale != 1.0f ? 1 : 0, seg_own, seg_gat, NS,
+                       dOmegaP.p, dOmegaQ.p, dKeyA.p, dValA.p);
+
+    // 3. sort by (block, owner, gathered); stable, so equal pairs keep their input order
+    int blk_bits = 1;
+    while ((1 << blk_bits) < NB) ++blk_bits;
+    const int end_bit = 2 * ID_BITS + blk_bits;
+    size_t tmp_bytes = 0;
+    PREP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, dKeyA.p, dKeyB.p, dValA.p, dValB.p, nnz, 0, end_bit, s));
+    Buf<char> dTmp;
+    dTmp.alloc(tmp_bytes);
+    PREP_TRY(hipcub::DeviceRadixSort::SortPairs(dTmp.p, tmp_bytes, dKeyA.p, dKeyB.p, dValA.p, dValB.p, nnz, 0, end_bit, s));
+
+    // 4. visit table: run-length encode the (block | owner) part of the sorted keys
+    if (nnz > 2147483647LL) throw std::invalid_argument("more than 2^31-1 ratings per trainer: shard the problem");
+    Buf<int> dRunLen, dRuns; // run keys go to dKeyA (free after the sort)
+    dRunLen.alloc(nnz);
+    dRuns.alloc(1);
+    hipcub::TransformInputIterator<unsigned long long, VisitKey, const unsigned long long *> vk(dKeyB.p, VisitKey());
+    size_t rle_bytes = 0;
+    PREP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, rle_bytes, vk, dKeyA.p, dRunLen.p, dRuns.p, (int)nnz, s));
+    Buf<char> dTmp2;
+    dTmp2.alloc(rle_bytes);
+    PREP_TRY(hipcub::DeviceRunLengthEncode::Encode(dTmp2.p, rle_bytes, vk, dKeyA.p, dRunLen.p, dRuns.p, (int)nnz, s));
+    int runs = 0;
+    PREP_TRY(hipMemcpyAsync(&runs, dRuns.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    PREP_TRY(hipStreamSynchronize(s));
+    std::vector<unsigned long long> run_key((size_t)runs);
+    std::vector<int> run_len((size_t)runs);
+    PREP_TRY(hipMemcpyAsync(run_key.data(), dKeyA.p, (size_t)runs * 8, hipMemcpyDeviceToHost, s));
+    PREP_TRY(hipMemcpyAsync(run_len.data(), dRunLen.p, (size_t)runs * 4, hipMemcpyDeviceToHost, s));
+    p.omega_p.resize(m);
+    p.omega_q.resize(n);
+    PREP_TRY(hipMemcpyAsync(p.omega_p.data(), dOmegaP.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+    PREP_TRY(hipMemcpyAsync(p.omega_q.data(), dOmegaQ.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    PREP_TRY(hipStreamSynchronize(s));
+
+    // 5. host: visits per block, packing into tasks (same code as the host builder)
+    std::vector<std::vector<Visit>> block_visits(NB);
+    {
+        std::vector<size_t> cnt(NB, 0);
+        for (int i = 0; i < runs; ++i) cnt[(size_t)(run_key[i] >> ID_BITS)]++;
+        for (int b = 0; b < NB; ++b) block_visits[b].reserve(cnt[b]);
+        uint64_t start = 0;
+        for (int i = 0; i < runs; ++i) {
+            const int b = (int)(run_key[i] >> ID_BITS);
+            block_visits[b].push_back({(uint32_t)(run_key[i] & ((1u << ID_BITS) - 1)), (uint32_t)run_len[i], start});
+            start += (uint64_t)run_len[i];
+        }
+    }
+    std::vector<Placement> places;
+    finish_plan(block_visits, cfg, p, places, threads);
+
+    // 6. entries on the device
+    EntryD *dEntries = nullptr;
+    PREP_TRY(hipMalloc((void **)&dEntries, (size_t)std::max<long long>(1, p.n_entries) * sizeof(EntryD)));
+    try {
+        Buf<Placement> dPlaces;
+        dPlaces.alloc(places.size());
+        PREP_TRY(hipMemcpyAsync(dPlaces.p, places.data(), places.size() * sizeof(Placement), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(fill_entries, dim3(grid_of(p.n_entries, cu_count)), dim3(256), 0, s, dEntries, p.n_entries);
+        hipLaunchKernelGGL(emit_entries, dim3(grid_of((long long)places.size(), cu_count)), dim3(256), 0, s,
+                           dPlaces.p, (long long)places.size(), dKeyB.p, dValB.p, G, dEntries);
+        PREP_TRY(hipGetLastError());
+        PREP_TRY(hipStreamSynchronize(s));
+    } catch (...) {
+        (void)hipFree(dEntries);
+        throw;
+    }
+    *d_entries_out = dEntries;
+}
+
+} // namespace mfx

@@ -1,0 +1,20 @@
+// prep.hpp -- device-side pre-processing (prep.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "kernels.hpp"
+#include "plan.hpp"
+
+namespace mfx {
+
+// ids must fit the 24-bit fields of the sort key (they do whenever they arrived as floats)
+bool device_prep_supported(int m, int n);
+
+// Build the stripe/task layout from ratings resident in HBM (dR: nnz mf_node records).  Fills the
+// host-side Plan (maps, counts, statistics, tasks, slot_task_ptr, n_entries) and returns the entry
+// array in a fresh hipMalloc'd buffer (*d_entries, caller frees).  Throws std::runtime_error /
+// std::invalid_argument / std::bad_alloc.
+void build_plan_device(const void *dR, long long nnz, int m, int n, const PlanConfig &cfg, int cu_count,
+                       hipStream_t s, Plan &p, EntryD **d_entries);
+
+} // namespace mfx

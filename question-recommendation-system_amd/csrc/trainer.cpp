@@ -19,6 +19,7 @@
 #include "../../include/mfx.h"
 #include "kernels.hpp"
 #include "plan.hpp"
+#include "prep.hpp"
 #include "synth.hpp"
 
 namespace {
@@ -59,6 +60,12 @@ template <class T> struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         n = 0;
+    }
+    void adopt(T *ptr, size_t count) // take ownership of a hipMalloc'd buffer
+    {
+        release();
+        p = ptr;
+        n = count;
     }
     ~DevBuf() { release(); }
 };
@@ -192,15 +199,15 @@ static int check_options(const mfx_options &opt)
     return MFX_OK;
 }
 
-static int create_impl(const mfx::Node *R, long long nnz, int m, int n, const mfx_options *opt_in,
-                       mfx_trainer **out)
+static int create_impl(const mfx::Node *R, const void *R_dev, long long nnz, int m, int n,
+                       const mfx_options *opt_in, mfx_trainer **out)
 {
     if (!out) return fail(MFX_E_ARG, "null output handle");
     *out = nullptr;
     if (!opt_in) return fail(MFX_E_ARG, "null options");
     mfx_options opt = *opt_in;
     if (int rc0 = check_options(opt)) return rc0;
-    if (!R || nnz <= 0 || m <= 0 || n <= 0) return fail(MFX_E_EMPTY, "train on an empty training set");
+    if ((!R && !R_dev) || nnz <= 0 || m <= 0 || n <= 0) return fail(MFX_E_EMPTY, "train on an empty training set");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -241,26 +248,62 @@ static int create_impl(const mfx::Node *R, long long nnz, int m, int n, const mf
 
     mfx::PlanConfig cfg = plan_config(opt, stripes, t->wgs_per_xcd, t->waves_per_wg);
 
+    // Pre-processing: on the device (prep.hip) unless forced to the host builder (MFX_HOST_PLAN=1)
+    // or the ids do not fit the sort key.  R may be host memory (uploaded once) or already in HBM.
+    const bool device_plan = env_int("MFX_HOST_PLAN", 0) == 0 && mfx::device_prep_supported(m, n);
+    mfx::EntryD *dev_entries = nullptr;
     try {
-        mfx::build_plan(R, nnz, m, n, cfg, t->plan);
+        if (device_plan) {
+            hipStream_t ps = nullptr;
+            hipError_t e = hipStreamCreateWithFlags(&ps, hipStreamNonBlocking);
+            if (e != hipSuccess) throw std::runtime_error(std::string("hipStreamCreate: ") + hipGetErrorString(e));
+            DevBuf<mfx::Node> up;
+            const void *dR = R_dev;
+            try {
+                if (!dR) {
+                    e = up.alloc((size_t)nnz);
+                    if (e == hipSuccess) e = hipMemcpyAsync(up.p, R, (size_t)nnz * sizeof(mfx::Node), hipMemcpyHostToDevice, ps);
+                    if (e != hipSuccess) throw std::runtime_error(std::string("upload of ratings: ") + hipGetErrorString(e));
+                    dR = up.p;
+                }
+                mfx::build_plan_device(dR, nnz, m, n, cfg, t->cu_count, ps, t->plan, &dev_entries);
+            } catch (...) {
+                (void)hipStreamDestroy(ps);
+                throw;
+            }
+            (void)hipStreamDestroy(ps);
+        } else {
+            std::vector<mfx::Node> host;
+            if (!R) { // ratings live in HBM but the host builder was asked for
+                host.resize((size_t)nnz);
+                hipError_t e = hipMemcpy(host.data(), R_dev, (size_t)nnz * sizeof(mfx::Node), hipMemcpyDeviceToHost);
+                if (e != hipSuccess) throw std::runtime_error(std::string("download of ratings: ") + hipGetErrorString(e));
+                R = host.data();
+            }
+            mfx::build_plan(R, nnz, m, n, cfg, t->plan);
+        }
     } catch (const std::bad_alloc &) {
         delete t;
         return fail(MFX_E_NOMEM, "out of host memory while building the plan");
-    } catch (const std::exception &e) {
+    } catch (const std::invalid_argument &e) {
         delete t;
         return fail(MFX_E_ARG, e.what());
+    } catch (const std::exception &e) {
+        delete t;
+        return fail(MFX_E_HIP, e.what());
     }
     mfx::Plan &p = t->plan;
     t->lambda_p = opt.lambda_p2 / p.scale;
     t->lambda_q = opt.lambda_q2 / p.scale;
     t->rk1 = (opt.rk_mode == 1 && p.ka > 8) ? (float)1.0 / (p.ka - 8) : 0.125f;
-    t->n_entries = (long long)p.entries.size();
+    t->n_entries = dev_entries ? p.n_entries : (long long)p.entries.size();
     t->n_tasks = (long long)p.tasks.size();
 
     int rc = MFX_OK;
     auto up = [&]() -> int {
         HIP_TRY(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
-        HIP_TRY(t->dEntries.alloc(p.entries.size()));
+        if (dev_entries) t->dEntries.adopt(dev_entries, (size_t)p.n_entries);
+        else HIP_TRY(t->dEntries.alloc(p.entries.size()));
         HIP_TRY(t->dTasks.alloc(p.tasks.size()));
         HIP_TRY(t->dSlotPtr.alloc(p.slot_task_ptr.size()));
         HIP_TRY(t->dSlotState.alloc((size_t)p.ns * p.ns));
@@ -271,8 +314,9 @@ static int create_impl(const mfx::Node *R, long long nnz, int m, int n, const mf
         HIP_TRY(t->dOmegaQ.alloc(n));
         HIP_TRY(t->dPmap.alloc(m));
         HIP_TRY(t->dQmap.alloc(n));
-        HIP_TRY(hipMemcpy(t->dEntries.p, p.entries.data(), p.entries.size() * sizeof(mfx::Entry),
-                          hipMemcpyHostToDevice));
+        if (!dev_entries)
+            HIP_TRY(hipMemcpy(t->dEntries.p, p.entries.data(), p.entries.size() * sizeof(mfx::Entry),
+                              hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(t->dTasks.p, p.tasks.data(), p.tasks.size() * sizeof(mfx::TaskDesc),
                           hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(t->dSlotPtr.p, p.slot_task_ptr.data(),
@@ -299,7 +343,7 @@ int mfx_trainer_create(const mfx_node *R_host, long long nnz, int m, int n, cons
                        mfx_trainer **out)
 {
     try {
-        return create_impl((const mfx::Node *)R_host, nnz, m, n, opt, out);
+        return create_impl((const mfx::Node *)R_host, nullptr, nnz, m, n, opt, out);
     } catch (const std::exception &e) {
         return fail(MFX_E_STATE, e.what());
     } catch (...) {
@@ -310,15 +354,13 @@ int mfx_trainer_create(const mfx_node *R_host, long long nnz, int m, int n, cons
 int mfx_trainer_create_device(const void *R_dev, long long nnz, int m, int n, const mfx_options *opt,
                               mfx_trainer **out)
 {
-    // Round 1: the stripe/task layout is built on the host, so device-resident ratings
-    // take one trip over PCIe here (one-off, outside every timed region).
-    if (!R_dev || nnz <= 0) return fail(MFX_E_EMPTY, "train on an empty training set");
+    // ratings already resident in HBM: nothing but the visit table crosses PCIe (prep.hip)
     try {
-        std::vector<mfx::Node> host((size_t)nnz);
-        HIP_TRY(hipMemcpy(host.data(), R_dev, (size_t)nnz * sizeof(mfx::Node), hipMemcpyDeviceToHost));
-        return create_impl(host.data(), nnz, m, n, opt, out);
+        return create_impl(nullptr, R_dev, nnz, m, n, opt, out);
     } catch (const std::exception &e) {
-        return fail(MFX_E_NOMEM, e.what());
+        return fail(MFX_E_STATE, e.what());
+    } catch (...) {
+        return fail(MFX_E_STATE, "unknown failure");
     }
 }
 
@@ -628,6 +670,18 @@ int mfx_trainer_set_model(mfx_trainer *t, const float *P, const float *Q, const 
     if (PG) HIP_TRY(hipMemcpy(t->dPG, PG, (size_t)p.m * 8, hipMemcpyHostToDevice));
     if (QG) HIP_TRY(hipMemcpy(t->dQG, QG, (size_t)p.n * 8, hipMemcpyHostToDevice));
     t->model_ready = true;
+    return MFX_OK;
+}
+
+int mfx_trainer_plan_copy(mfx_trainer *t, void *entries, void *tasks, long long *slot_task_ptr)
+{
+    if (!t) return fail(MFX_E_ARG, "null trainer");
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const mfx::Plan &p = t->plan;
+    if (entries) HIP_TRY(hipMemcpy(entries, t->dEntries.p, (size_t)t->n_entries * sizeof(mfx::EntryD), hipMemcpyDeviceToHost));
+    if (tasks) HIP_TRY(hipMemcpy(tasks, t->dTasks.p, (size_t)t->n_tasks * sizeof(mfx::TaskDescD), hipMemcpyDeviceToHost));
+    if (slot_task_ptr) memcpy(slot_task_ptr, p.slot_task_ptr.data(), p.slot_task_ptr.size() * sizeof(long long));
     return MFX_OK;
 }
 

@@ -231,3 +231,43 @@ def test_config2_full_size(pkg):
     assert (np.diff(tr) < 0).all()
     assert abs(tr[0] - 1.2245) / 1.2245 < 0.01          # epoch 0 starts from the same factors
     assert abs(rm - 0.94767) / 0.94767 < 0.03, rm        # observed 0.925-0.928: the GPU path is slightly ahead
+
+
+@pytest.mark.parametrize("shape", [(3000, 2000, 90000, 32), (500, 4000, 60000, 8), (20000, 9000, 1500000, 64)])
+def test_device_preprocessing_equals_host_builder(pkg, orc, shape):
+    """prep.hip (statistics, relabel, scale, radix sort, visit table on the GPU) must produce the very layout
+    plan.cpp builds on the host: integer / index work, bit-exact -- entries, tasks, block table, maps, counts."""
+    import os
+    m, n, nnz, k = shape
+    R = pkg.synth_host(12, 0, nnz, m, n)
+    hp = pkg.HostPlan(R, m, n, k=k)
+    # the same statistics for both (a double sum in another order may differ in the last bit)
+    kw = dict(k=k, use_stats=1, stats_avg=float(hp.view.avg), stats_std=float(hp.view.std_dev))
+    t = pkg.Trainer(R, m, n, **kw)
+    assert os.environ.get("MFX_HOST_PLAN", "0") == "0"
+    e, ts, sp = t.plan_copy()
+    pm, qm = t.maps()
+    assert np.array_equal(pm, hp.p_map) and np.array_equal(qm, hp.q_map)
+    assert np.array_equal(sp, hp.slot_task_ptr)
+    assert np.array_equal(ts, hp.tasks)
+    assert np.array_equal(e, hp.entries)
+    # statistics computed on the device agree with collect_info to float precision
+    t2 = pkg.Trainer(R, m, n, k=k)
+    assert abs(t2.info.avg - hp.view.avg) <= 1e-6 * abs(hp.view.avg) and abs(t2.info.std_dev - hp.view.std_dev) <= 1e-6 * hp.view.std_dev
+    t2.init_model(); P2, Q2, _, _ = t2.get_model()
+    P0, Q0 = hp.init_factors()
+    assert np.array_equal(P0.view(np.uint32), P2.view(np.uint32)) and np.array_equal(Q0.view(np.uint32), Q2.view(np.uint32))
+    # and from ratings that never leave HBM
+    import torch
+    d = torch.from_numpy(R.view(np.int32).reshape(-1)).cuda()
+    t3 = pkg.Trainer(None, m, n, opts=pkg.default_options(**kw), device_ptr=d.data_ptr(), nnz=nnz)
+    e3, ts3, sp3 = t3.plan_copy()
+    assert np.array_equal(e3, hp.entries) and np.array_equal(ts3, hp.tasks)
+    for x in (t, t2, t3):
+        x.close()
+
+
+def test_device_preprocessing_rejects_bad_ids(pkg):
+    R = np.array([(0, 0, 1.0), (5, 0, 2.0)], dtype=pkg.NODE)
+    with pytest.raises(pkg.MfxError, match="outside"):
+        pkg.Trainer(R, 2, 1, k=8)
