@@ -271,3 +271,20 @@ def test_device_preprocessing_rejects_bad_ids(pkg):
     R = np.array([(0, 0, 1.0), (5, 0, 2.0)], dtype=pkg.NODE)
     with pytest.raises(pkg.MfxError, match="outside"):
         pkg.Trainer(R, 2, 1, k=8)
+
+
+def test_checkpoint_resume(pkg):
+    """Training state = (P, Q, PG, QG) in internal layout + the epoch count (the reference only persists the
+    model, mf.cpp:4184-4225).  A run cut in two and resumed in a fresh trainer lands where the uncut run does."""
+    m, n, nnz, k = 30000, 20000, 3000000, 32
+    R = pkg.synth_host(21, 0, nnz, m, n)
+    a = pkg.Trainer(R, m, n, k=k); a.init_model(); a.train(10); full = a.rmse(); a.close()
+    b = pkg.Trainer(R, m, n, k=k); b.init_model(); b.train(5)
+    state = b.get_model(); b.close()
+    c = pkg.Trainer(R, m, n, k=k); c.set_model(*state)
+    for _ in range(5):
+        c.epoch(slow_only=False)
+    c.sync(); resumed = c.rmse()
+    P, Q, PG, QG = c.get_model(); c.close()
+    assert abs(resumed - full) / full < RMSE_RTOL
+    assert (PG >= state[2]).all() and (QG >= state[3]).all()  # accumulators carried on, not reset
