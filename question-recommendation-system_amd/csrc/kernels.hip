@@ -63,11 +63,6 @@ __device__ __forceinline__ int xcc_id()
     return x;
 }
 
-__device__ __forceinline__ int aload(const int *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // factor loads: served by the XCD's L2, never by a stale per-CU L1 line
 #ifndef MFX_LD_PLAIN
 __device__ __forceinline__ f4 ld_row(const float *p) { return __builtin_nontemporal_load((const f4 *)p); }

@@ -8,6 +8,7 @@
 //     nullptr / lens = 0 (the reference crashes, SURVEY.md 8b "Errors");
 //   * the worker loop cannot dead-lock at shutdown (reference quirk Q2);
 //   * nr_threads / nr_bins are accepted and ignored: the schedule is the device's.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +18,7 @@
 #include <limits>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mf.h"
@@ -252,21 +254,43 @@ float *utility_train(float *train_data, int train_triplet_num, double p_l2, doub
     lens = 0;
     try {
         if (train_data == nullptr || train_triplet_num <= 0) return nullptr;
-        // read_triplet, reference mf/mf.cpp:3367-3394 (64-bit index: no overflow past 715 M)
+        // read_triplet, reference mf/mf.cpp:3367-3394 (64-bit index: no overflow past 715 M),
+        // converted by a few host threads
         std::vector<mf_node> R((size_t)train_triplet_num);
         mf_problem tr;
         tr.m = 0;
         tr.n = 0;
         tr.nnz = train_triplet_num;
-        for (long long j = 0; j < train_triplet_num; ++j) {
-            mf_node N;
-            N.u = (mf_int)train_data[3 * j];
-            N.v = (mf_int)train_data[3 * j + 1];
-            N.r = train_data[3 * j + 2];
-            if (N.u < 0 || N.v < 0) return nullptr;
-            if (N.u + 1 > tr.m) tr.m = N.u + 1;
-            if (N.v + 1 > tr.n) tr.n = N.v + 1;
-            R[j] = N;
+        {
+            const long long N = train_triplet_num;
+            unsigned hc = std::thread::hardware_concurrency();
+            const int nt = (int)std::max<long long>(1, std::min<long long>(hc ? hc : 1, N / 262144 + 1));
+            std::vector<int> mm(nt, 0), nn(nt, 0), neg(nt, 0);
+            std::vector<std::thread> pool;
+            for (int ti = 0; ti < nt; ++ti)
+                pool.emplace_back([&, ti]() {
+                    const long long lo = N * ti / nt, hi = N * (ti + 1) / nt;
+                    int mx = 0, nx = 0, bad = 0;
+                    for (long long j = lo; j < hi; ++j) {
+                        mf_node nd;
+                        nd.u = (mf_int)train_data[3 * j];
+                        nd.v = (mf_int)train_data[3 * j + 1];
+                        nd.r = train_data[3 * j + 2];
+                        bad |= (nd.u < 0) | (nd.v < 0);
+                        if (nd.u + 1 > mx) mx = nd.u + 1;
+                        if (nd.v + 1 > nx) nx = nd.v + 1;
+                        R[(size_t)j] = nd;
+                    }
+                    mm[ti] = mx;
+                    nn[ti] = nx;
+                    neg[ti] = bad;
+                });
+            for (auto &th : pool) th.join();
+            for (int ti = 0; ti < nt; ++ti) {
+                if (neg[ti]) return nullptr;
+                tr.m = std::max(tr.m, mm[ti]);
+                tr.n = std::max(tr.n, nn[ti]);
+            }
         }
         tr.R = R.data();
 

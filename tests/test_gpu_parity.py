@@ -289,3 +289,29 @@ def test_checkpoint_resume(pkg):
     P, Q, PG, QG = c.get_model(); c.close()
     assert abs(resumed - full) / full < RMSE_RTOL
     assert (PG >= state[2]).all() and (QG >= state[3]).all()  # accumulators carried on, not reset
+
+
+def test_mf_my_train_text_round_trip(pkg, orc, tmp_path):
+    """mf::mf_my_train (reference mf/mf.cpp:3397-3413): "u v r" text file in, LIBMF text model out
+    (mf.cpp:4143-4225), 40 iterations with the default parameters (k=8)."""
+    import ctypes as C
+    m, n, nnz = 3000, 2000, 150000
+    R = pkg.synth_host(5, 0, nnz, m, n)
+    src, dst = tmp_path / "ratings.txt", tmp_path / "model.txt"
+    with open(src, "w") as f:
+        for u, v, r in R:
+            f.write("%d %d %r\n" % (u, v, float(r)))
+    rc = getattr(pkg.lib(), pkg.MANGLED["mf_my_train"])(str(src).encode(), str(dst).encode())
+    assert rc == 0
+    lines = open(dst).read().splitlines()
+    assert [ln.split()[0] for ln in lines[:5]] == ["f", "m", "n", "k", "b"]
+    hdr = {ln.split()[0]: ln.split()[1] for ln in lines[:5]}
+    assert (int(hdr["f"]), int(hdr["m"]), int(hdr["n"]), int(hdr["k"])) == (0, m, n, 8)
+    assert len(lines) == 5 + m + n and lines[5].startswith("p0 T") and lines[5 + m].startswith("q0 T")
+    P = np.array([[float(x) for x in ln.split()[2:]] for ln in lines[5:5 + m]], dtype=np.float32)
+    Q = np.array([[float(x) for x in ln.split()[2:]] for ln in lines[5 + m:]], dtype=np.float32)
+    arr = np.concatenate([[0, m, n, 8, float(hdr["b"])], P.ravel(), Q.ravel()]).astype(np.float32)
+    want = orc.rmse(R, orc.train(R, m, n, k=8, iters=40))
+    got = orc.rmse(R, arr)
+    assert abs(got - want) / want < 0.03, (got, want)  # the text format keeps 6 significant digits
+    assert getattr(pkg.lib(), pkg.MANGLED["mf_my_train"])(b"/nonexistent/file", str(dst).encode()) == -1
