@@ -132,9 +132,81 @@ __global__ __launch_bounds__(256) void emit_entries(const Placement *pl, long lo
     }
 }
 
+// ---- init_model on the device ----------------------------------------------------------------
+// The reference draws the initial factors from ONE std::minstd_rand0 stream, P rows then Q rows in
+// internal order, k draws per row that has ratings (mf.cpp:952-1007).  x_{i+1} = 16807 x_i mod (2^31-1)
+// can be entered anywhere: x_{i+j} = 16807^j x_i, so every row starts from its own stream position
+// (k times the number of seen rows before it, an exclusive scan) and the result is bit-identical.
+
+__global__ __launch_bounds__(256) void seen_flags(const int *omega_p, int m, const int *omega_q, int n,
+                                                  unsigned long long *flag)
+{
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nth = (long long)gridDim.x * blockDim.x, rows = (long long)m + n;
+    for (long long i = tid; i < rows; i += nth) flag[i] = (i < m ? omega_p[i] : omega_q[i - m]) > 0 ? 1ull : 0ull;
+}
+
+__device__ __forceinline__ unsigned minstd_mul(unsigned a, unsigned b)
+{
+    return (unsigned)(((unsigned long long)a * b) % 2147483647ull);
+}
+
+__global__ __launch_bounds__(256) void init_rows(const unsigned long long *seen_before, const int *omega_p, int m,
+                                                 const int *omega_q, int n, int k, int ka, float scale,
+                                                 float *P, float *Q)
+{
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nth = (long long)gridDim.x * blockDim.x, rows = (long long)m + n;
+    for (long long i = tid; i < rows; i += nth) {
+        const bool isP = i < m;
+        const long long row = isP ? i : i - m;
+        float *dst = (isP ? P : Q) + row * ka;
+        const bool seen = (isP ? omega_p[row] : omega_q[row]) > 0;
+        if (seen) {
+            unsigned long long steps = seen_before[i] * (unsigned long long)k; // draws before this row
+            unsigned mult = 1u, base = 16807u;                                  // 16807^steps mod (2^31-1)
+            while (steps) {
+                if (steps & 1ull) mult = minstd_mul(mult, base);
+                base = minstd_mul(base, base);
+                steps >>= 1;
+            }
+            unsigned x = mult; // default seed 1
+            for (int d = 0; d < k; ++d) {
+                x = minstd_mul(x, 16807u);
+                float f = (float)(x - 1u) * 4.6566128730773926e-10f; // / 2^31, exact
+                if (!(f < 1.0f)) f = 0.99999994f;                    // generate_canonical's clamp
+                dst[d] = f * scale;
+            }
+        } else {
+            for (int d = 0; d < k; ++d) dst[d] = __builtin_nanf("");
+        }
+        for (int d = k; d < ka; ++d) dst[d] = 0.0f;
+    }
+}
+
 int grid_of(long long n, int cu) { return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)cu * 8)); }
 
 } // namespace
+
+void init_factors_device(const int *d_omega_p, int m, const int *d_omega_q, int n, int k, int ka, int cu_count,
+                         hipStream_t s, float *dP, float *dQ)
+{
+    const long long rows = (long long)m + n;
+    Buf<unsigned long long> dFlag, dScan;
+    dFlag.alloc((size_t)rows);
+    dScan.alloc((size_t)rows);
+    hipLaunchKernelGGL(seen_flags, dim3(grid_of(rows, cu_count)), dim3(256), 0, s, d_omega_p, m, d_omega_q, n, dFlag.p);
+    size_t tmp_bytes = 0;
+    PREP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, dFlag.p, dScan.p, (int)rows, s));
+    Buf<char> dTmp;
+    dTmp.alloc(tmp_bytes);
+    PREP_TRY(hipcub::DeviceScan::ExclusiveSum(dTmp.p, tmp_bytes, dFlag.p, dScan.p, (int)rows, s));
+    const float scale = (float)std::sqrt(1.0 / k); // mf.cpp:971
+    hipLaunchKernelGGL(init_rows, dim3(grid_of(rows, cu_count)), dim3(256), 0, s, dScan.p, d_omega_p, m, d_omega_q,
+                       n, k, ka, scale, dP, dQ);
+    PREP_TRY(hipGetLastError());
+    PREP_TRY(hipStreamSynchronize(s));
+}
 
 bool device_prep_supported(int m, int n) { return m <= (1 << ID_BITS) && n <= (1 << ID_BITS); }
 

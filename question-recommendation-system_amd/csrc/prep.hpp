@@ -17,4 +17,9 @@ bool device_prep_supported(int m, int n);
 void build_plan_device(const void *dR, long long nnz, int m, int n, const PlanConfig &cfg, int cu_count,
                        hipStream_t s, Plan &p, EntryD **d_entries);
 
+// init_model (reference mf/mf.cpp:952-1007) on the device, bit-identical to the host's init_factors:
+// row counts (internal order) already in HBM, factors written with stride ka.
+void init_factors_device(const int *d_omega_p, int m, const int *d_omega_q, int n, int k, int ka, int cu_count,
+                         hipStream_t s, float *dP, float *dQ);
+
 } // namespace mfx

@@ -330,6 +330,7 @@ static int create_impl(const mfx::Node *R, const void *R_dev, long long nnz, int
     };
     rc = up();
     if (rc != MFX_OK) {
+        if (dev_entries && t->dEntries.p != dev_entries) (void)hipFree(dev_entries); // not adopted yet
         delete t;
         return rc;
     }
@@ -416,13 +417,19 @@ int mfx_trainer_init_model_counts(mfx_trainer *t, const int *omega_p, const int 
             oq.resize(p.n);
             for (int i = 0; i < p.n; ++i) oq[p.q_map[i]] = omega_q[i];
         }
-        std::vector<float> P, Q;
-        mfx::init_factors(p, omega_p ? op.data() : nullptr, omega_q ? oq.data() : nullptr, P, Q,
-                          env_int("MFX_HOST_THREADS", 0));
-        HIP_TRY(hipMemcpy(t->dP, P.data(), P.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(t->dQ, Q.data(), Q.size() * 4, hipMemcpyHostToDevice));
         if (omega_p) HIP_TRY(hipMemcpy(t->dOmegaP.p, op.data(), (size_t)p.m * 4, hipMemcpyHostToDevice));
         if (omega_q) HIP_TRY(hipMemcpy(t->dOmegaQ.p, oq.data(), (size_t)p.n * 4, hipMemcpyHostToDevice));
+        if (env_int("MFX_HOST_INIT", 0) == 0) {
+            // the reference's single minstd_rand0 stream, entered per row by skip-ahead (prep.hip)
+            mfx::init_factors_device(t->dOmegaP.p, p.m, t->dOmegaQ.p, p.n, p.k, p.ka, t->cu_count, t->stream,
+                                     t->dP, t->dQ);
+        } else {
+            std::vector<float> P, Q;
+            mfx::init_factors(p, omega_p ? op.data() : nullptr, omega_q ? oq.data() : nullptr, P, Q,
+                              env_int("MFX_HOST_THREADS", 0));
+            HIP_TRY(hipMemcpy(t->dP, P.data(), P.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(t->dQ, Q.data(), Q.size() * 4, hipMemcpyHostToDevice));
+        }
         // PG, QG <- 1 (reference mf/mf.cpp:2835)
         HIP_TRY(mfx::launch_fill(t->dPG, 2LL * p.m, 1.0f, grid_for(2LL * p.m, t->cu_count), t->stream));
         HIP_TRY(mfx::launch_fill(t->dQG, 2LL * p.n, 1.0f, grid_for(2LL * p.n, t->cu_count), t->stream));
@@ -430,8 +437,10 @@ int mfx_trainer_init_model_counts(mfx_trainer *t, const int *omega_p, const int 
         t->model_ready = true;
         t->epochs_done = 0;
         return MFX_OK;
-    } catch (const std::exception &e) {
+    } catch (const std::bad_alloc &e) {
         return fail(MFX_E_NOMEM, e.what());
+    } catch (const std::exception &e) {
+        return fail(MFX_E_HIP, e.what());
     }
 }
 
