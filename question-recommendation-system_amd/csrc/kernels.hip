@@ -72,6 +72,19 @@ __device__ __forceinline__ f4 ld_row(const float *p) { return *(const f4 *)p; }
 __device__ __forceinline__ f2 ld_acc(const float *p) { return *(const f2 *)p; }
 #endif
 
+#ifdef MFX_STAMPS
+// Diagnostic build only (`make diag` -> lib_diag/): s_memtime stamps around the segments of a step.
+// The sums go to a buffer of their own; no result depends on them; the shipped library has none of this.
+#define STAMP(t)                                                                                 \
+    do {                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    } while (0)
+#else
+#define STAMP(t) do { } while (0)
+#endif
+
 // ---- the SGD round ----------------------------------------------------------------------
 
 // LANES  lanes per rating (power of two, LANES*4 >= k_a)
@@ -100,12 +113,18 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
     // the host's cursor check reports the unfinished blocks -- never a silent wrong answer).
     const int rank = (int)(threadIdx.x >> 6) < a.active_waves ? a.xcc_rank[xcc_id() & 15] : -1;
     double lsum = 0.0;
+#ifdef MFX_STAMPS
+    unsigned long long tk0 = 0, tk1 = 0, ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+    unsigned long long c_task = 0, c_wait = 0, c_win = 0, c_rest = 0, n_steps = 0, n_tasks = 0, c_total = 0, tstart = 0;
+    STAMP(tstart);
+#endif
     if (rank >= 0)
         for (int slot = rank; slot < a.ns; slot += a.n_xcc) {
             const long long tbeg = a.slot_task_ptr[slot];
             const int ntask = (int)(a.slot_task_ptr[slot + 1] - tbeg);
             for (;;) {
                 int c = 0;
+                STAMP(tk0);
                 if (lane == 0) c = atomicAdd(&a.slot_cursor[slot], 1);
                 c = __builtin_amdgcn_readfirstlane(c);
                 if (c >= ntask) break;
@@ -130,7 +149,13 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     if (lane_ok) on = ld_row(a.own_rows + (size_t)pf * ka + d0);
                     ogn = ld_acc(a.own_acc + (size_t)pf * 2);
                 }
+                STAMP(tk1);
+#ifdef MFX_STAMPS
+                c_task += tk1 - tk0;
+                n_tasks++;
+#endif
                 for (int step = 0; step < nsteps; ++step) {
+                    STAMP(ts0);
                     // ---- issue every load of this step, then one wait ----
                     // (nothing that a load returns is touched after the stores at the bottom, so
                     //  the next step's loads go out right behind them)
@@ -176,6 +201,7 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     asm volatile("" : "+v"(on.x), "+v"(on.y), "+v"(on.z), "+v"(on.w), "+v"(ogn.x), "+v"(ogn.y));
                     asm volatile("" : "+v"(e1.own), "+v"(e1.gat), "+v"(e1.r));
 
+                    STAMP(ts1);
                     // ---- compute: z = p.q (calc_z), err = r - z (prepare_for_sg_update) ----
                     float z = o.x * g.x + o.y * g.y + o.z * g.z + o.w * g.w;
                     z = group_sum<LANES>(z);
@@ -201,6 +227,7 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     // the gathered row goes back first: the time between its load and this store
                     // is the window in which another wave's update of the same row is lost
                     if (act && lane_ok) *(f4 *)grow = g;
+                    STAMP(ts2);
                     const float sg0 = group_sum<LANES>(slot1 ? 0.0f : sg);
                     gg.x = gg.x + sg0 * rk0;
                     if (!SLOW) {
@@ -214,6 +241,13 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                         const float so1 = group_sum<LANES>(slot1 ? so : 0.0f);
                         og1 = og1 + so1 * rk1;
                     }
+                    STAMP(ts3);
+#ifdef MFX_STAMPS
+                    c_wait += ts1 - ts0;
+                    c_win += ts2 - ts1;
+                    c_rest += ts3 - ts2;
+                    n_steps++;
+#endif
                 }
                 if (cur != NONE) {
                     if (lane_ok) *(f4 *)(a.own_rows + (size_t)cur * ka + d0) = o;
@@ -223,6 +257,17 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
             }
         }
 
+#ifdef MFX_STAMPS
+    {
+        unsigned long long tend;
+        STAMP(tend);
+        c_total = tend - tstart;
+        if (lane == 0 && a.stamps) {
+            unsigned long long *o = a.stamps + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+            o[0] += c_task; o[1] += c_wait; o[2] += c_win; o[3] += c_rest; o[4] += n_steps; o[5] += n_tasks; o[6] += c_total; o[7] += 1;
+        }
+    }
+#endif
     // online loss (Scheduler::get_loss, mf.cpp:237-241): wave -> workgroup through LDS, then ONE
     // double atomic per workgroup, spread over LOSS_SLOTS addresses (every wave adding to one
     // word serialises ~1500 atomics at the end of a short launch)

@@ -26,6 +26,9 @@ struct RoundArgs {
     int ka, slow_only, ns;
     int n_xcc;                      // XCDs that take work
     int active_waves;               // waves of a workgroup that take work (1..4)
+#ifdef MFX_STAMPS
+    unsigned long long *stamps;     // diagnostic build only: 8 cycle sums per wave (kernels.hip, STAMP)
+#endif
     signed char xcc_rank[16];       // HW_REG_XCC_ID -> rank in [0, n_xcc), -1 = takes no work
 };
 

@@ -491,6 +491,29 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
     a.ns = ns;
     a.n_xcc = t->xcd_count;
     a.active_waves = t->waves_per_wg;
+#ifdef MFX_STAMPS
+    { // diagnostic build (`make diag`): where do the cycles of a wave go?  MFX_STAMPS_DUMP=1 prints and resets the sums
+        static unsigned long long *g_stamps = nullptr;
+        const size_t words = (size_t)65536 * 8;
+        if (!g_stamps) {
+            (void)hipMalloc((void **)&g_stamps, words * sizeof(unsigned long long));
+            (void)hipMemset(g_stamps, 0, words * sizeof(unsigned long long));
+        }
+        a.stamps = g_stamps;
+        if (getenv("MFX_STAMPS_DUMP")) {
+            std::vector<unsigned long long> h(words);
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(h.data(), g_stamps, words * 8, hipMemcpyDeviceToHost);
+            unsigned long long s8[8] = {0};
+            for (size_t i = 0; i < words; ++i) s8[i % 8] += h[i];
+            fprintf(stderr, "stamps: waves*launches %llu steps %llu tasks %llu | per step: wait %.0f window %.0f rest %.0f cycles | "
+                            "per task: fetch+stage %.0f | wave total %.0f cycles per launch\n",
+                    s8[7], s8[4], s8[5], (double)s8[1] / s8[4], (double)s8[2] / s8[4], (double)s8[3] / s8[4],
+                    (double)s8[0] / s8[5], (double)s8[6] / s8[7]);
+            (void)hipMemset(g_stamps, 0, words * 8);
+        }
+    }
+#endif
     memcpy(a.xcc_rank, t->xcc_rank, sizeof(a.xcc_rank));
     const int grid = t->xcd_count * t->wgs_per_xcd; // workgroups are dealt round-robin over XCDs
     const int i_begin = (int)((long long)part * ns / nparts), i_end = (int)((long long)(part + 1) * ns / nparts);
