@@ -81,6 +81,11 @@ __device__ __forceinline__ f2 ld_acc(const float *p) { return *(const f2 *)p; }
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");               \
         __builtin_amdgcn_sched_barrier(0);                                                       \
     } while (0)
+// 100 MHz wall clock shared by the whole device (s_memtime counters of different CUs are offset)
+#define RSTAMP(t)                                                                                \
+    do {                                                                                         \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");           \
+    } while (0)
 #else
 #define STAMP(t) do { } while (0)
 #endif
@@ -94,19 +99,23 @@ template <int LANES, bool FULL, bool SLOW>
 __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
 {
     constexpr int G = 64 / LANES;
+    constexpr int EBLK = 128; // entries per block of the entry stream (two per lane); EBLK/G steps
+    static_assert(EBLK / G >= 4, "a block of the entry stream must span at least four steps");
     constexpr unsigned NONE = 0xFFFFFFFFu, IDMASK = 0x7FFFFFFFu;
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    __shared__ u4 ering_all[4][2 * EBLK]; // per wave: a ring of two blocks, 16-byte slots
+    u4 *const ering = ering_all[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
     const int lig = lane % LANES;
     const int grp = lane / LANES;
     const int d0 = lig * 4;
-    const int ka = a.ka;
+    const int ka = FULL ? LANES * 4 : a.ka; // a compile-time constant when every lane carries factors
     const bool lane_ok = FULL || d0 < ka;
     const bool slot1 = d0 >= 8;               // dims [8,k_a) use accumulator slot 1
     const bool upd = lane_ok && !(SLOW && slot1);
     const float lam_o = a.lambda_own, lam_g = a.lambda_gat, eta = a.eta;
     const float rk0 = 0.125f, rk1 = a.rk1;
     const f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    const EntryD pad = {0u, -1, 0.0f};
 
     // Blocks ("slots") of this round that belong to this wave's XCD: rank, rank+X, ...
     // (xcc_rank comes from a probe launch; an XCD the probe did not see takes no work and
@@ -116,7 +125,9 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
 #ifdef MFX_STAMPS
     unsigned long long tk0 = 0, tk1 = 0, ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
     unsigned long long c_task = 0, c_wait = 0, c_win = 0, c_rest = 0, n_steps = 0, n_tasks = 0, c_total = 0, tstart = 0;
+    unsigned long long rstart = 0, rend = 0;
     STAMP(tstart);
+    RSTAMP(rstart);
 #endif
     if (rank >= 0)
         for (int slot = rank; slot < a.ns; slot += a.n_xcc) {
@@ -129,9 +140,14 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                 c = __builtin_amdgcn_readfirstlane(c);
                 if (c >= ntask) break;
 
+                // the descriptor is the same for every lane: keep it in SGPRs, so that the step loop
+                // below branches on scalars (real branches, no exec-masked loop exits)
                 const TaskDescD td = a.tasks[tbeg + c];
-                const EntryD *ep = a.entries + td.off + grp;
-                const int nsteps = (int)td.nsteps;
+                const unsigned long long toff =
+                    ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(td.off >> 32)) << 32) |
+                    (unsigned)__builtin_amdgcn_readfirstlane((int)(td.off & 0xFFFFFFFFu));
+                const EntryD *ep = a.entries + toff + grp;
+                const int nsteps = __builtin_amdgcn_readfirstlane((int)td.nsteps);
 
                 unsigned cur = NONE;  // owner row held in registers
                 f4 o = zero4;
@@ -141,14 +157,57 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                 f2 ogn = {1.0f, 1.0f};
                 float tsum = 0.0f;
 
-                // two entries of look-ahead: e (this step), e1 (next), e2 (being loaded)
-                EntryD e = ep[0];
-                EntryD e1 = nsteps > 1 ? ep[G] : pad;
+                // ---- the entry stream ----
+                // The entries of a task are streamed once from HBM, so their loads are the slow ones
+                // (a microsecond and more under load) and, vmcnt being in-order, the first wait
+                // behind such a load waits for it.  One entry load per step therefore costs one HBM
+                // latency per step.  Instead the wave fetches EBLK entries (EBLK/G steps) with two
+                // loads per lane and parks them in its own LDS ring of two such blocks; the steps
+                // take their entries from LDS (lgkmcnt, a queue of its own).  That leaves one slow
+                // load per block, issued right behind a wait so that it has a whole step to arrive.
+                const EntryD *const ebase = a.entries + toff;
+                const int nent = nsteps * G;
+                auto fetch_block = [&](int blk, EntryD &r0, EntryD &r1) { // lane -> its two entries of a block
+                    const int i0 = blk * EBLK + lane, i1 = i0 + 64;
+                    r0 = ebase[i0 < nent ? i0 : nent - 1];
+                    r1 = ebase[i1 < nent ? i1 : nent - 1];
+                };
+                auto park_block = [&](int blk, const EntryD &r0, const EntryD &r1) {
+                    const int i0 = (blk * EBLK + lane) & (2 * EBLK - 1);
+                    ering[i0] = u4{r0.own, (unsigned)r0.gat, __builtin_bit_cast(unsigned, r0.r), 0u};
+                    ering[i0 + 64] = u4{r1.own, (unsigned)r1.gat, __builtin_bit_cast(unsigned, r1.r), 0u};
+                };
+                auto entry_of = [&](int step) { // this lane group's entry of a step
+#ifdef MFX_ENTRY_GLOBAL // experiment/bisect: straight from memory
+                    return ebase[(step < nsteps ? step : nsteps - 1) * G + grp];
+#else
+                    const u4 v = ering[(step * G + grp) & (2 * EBLK - 1)];
+                    const unsigned rbits = v.z; // (bit_cast straight from the swizzle v.z takes element 0 with this hipcc)
+                    return EntryD{v.x, (int)v.y, __builtin_bit_cast(float, rbits)};
+#endif
+                };
+                EntryD r0, r1;
+                fetch_block(0, r0, r1);
+                park_block(0, r0, r1);
+                EntryD e = entry_of(0);
                 if (e.gat >= 0) { // every list starts with a visit: fetch its owner row now
                     pf = e.own & IDMASK;
                     if (lane_ok) on = ld_row(a.own_rows + (size_t)pf * ka + d0);
                     ogn = ld_acc(a.own_acc + (size_t)pf * 2);
                 }
+                // Every memory operation of a step goes out in ONE burst at the end of its update
+                // window, in this order: row store, accumulator store, the NEXT step's gathered row
+                // and accumulators, the next visit's owner row.  The wait at the top of the next step
+                // then covers exactly that burst, and the owner update of a step runs under the L2
+                // round trip of the next one.  The time between a row's load and its store (the
+                // window in which a concurrent update of the same row is lost) keeps its length; it
+                // only starts earlier.
+                // Pad entries and lanes past k_a read and write the scratch row instead (a zero row
+                // that nothing ever changes), so that every row/accumulator access is unconditional.
+                float *grow = (e.gat >= 0 && lane_ok ? a.gat_rows + (size_t)e.gat * ka : a.scratch) + d0;
+                float *gacc = e.gat >= 0 ? a.gat_acc + (size_t)e.gat * 2 : a.scratch + SCRATCH_ROW;
+                f4 gn = ld_row(grow);
+                f2 ggn = ld_acc(gacc);
                 STAMP(tk1);
 #ifdef MFX_STAMPS
                 c_task += tk1 - tk0;
@@ -156,19 +215,12 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
 #endif
                 for (int step = 0; step < nsteps; ++step) {
                     STAMP(ts0);
-                    // ---- issue every load of this step, then one wait ----
-                    // (nothing that a load returns is touched after the stores at the bottom, so
-                    //  the next step's loads go out right behind them)
-                    const int s2 = step + 2 < nsteps ? step + 2 : nsteps - 1;
-                    EntryD e2 = ep[(size_t)s2 * G];
-                    if (step + 2 >= nsteps) e2.gat = -1;
+                    // (read under the wait below; stale past the end of the list, see nact; the
+                    //  block it may belong to was parked one step ago)
+                    const EntryD enext = entry_of(step + 1);
                     const bool act = e.gat >= 0;
                     const unsigned id = e.own & IDMASK;
-                    float *grow = a.gat_rows + (size_t)(act ? e.gat : 0) * ka + d0;
-                    float *gacc = a.gat_acc + (size_t)(act ? e.gat : 0) * 2;
-                    f4 g = zero4;
-                    if (lane_ok) g = ld_row(grow);
-                    f2 gg = ld_acc(gacc);
+                    const float rating = e.r;
                     const bool newvisit = act && (e.own >> 31) && id != cur;
                     if (newvisit) { // switch the owner row: write the old one back, take the prefetched one
                         if (cur != NONE) {
@@ -184,27 +236,26 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                         og1 = ogn.y;
                         cur = id;
                     }
-                    // prefetch the owner row of the visit that starts at the next step
-                    const unsigned id1 = e1.own & IDMASK;
-                    if (e1.gat >= 0 && (e1.own >> 31) && id1 != cur) {
-                        pf = id1;
-                        if (lane_ok) on = ld_row(a.own_rows + (size_t)id1 * ka + d0);
-                        ogn = ld_acc(a.own_acc + (size_t)id1 * 2);
-                    }
-                    const float rating = e.r;
-                    e = e1; // rotate the look-ahead here, before the stores
-                    e1 = e2;
-                    // One explicit settle point for every load of this step.  Without it hipcc
+                    f4 g = gn;
+                    f2 gg = ggn;
+                    float *const grow_c = grow, *const gacc_c = gacc;
+                    // One explicit settle point for the loads this step consumes.  Without it hipcc
                     // re-waits with vmcnt(0) at later uses of these registers, i.e. behind the
                     // stores below, which costs a full store round trip per step.
                     asm volatile("" : "+v"(g.x), "+v"(g.y), "+v"(g.z), "+v"(g.w), "+v"(gg.x), "+v"(gg.y));
-                    asm volatile("" : "+v"(on.x), "+v"(on.y), "+v"(on.z), "+v"(on.w), "+v"(ogn.x), "+v"(ogn.y));
-                    asm volatile("" : "+v"(e1.own), "+v"(e1.gat), "+v"(e1.r));
+                    // block bookkeeping, on scalars: fetch the next block at the start of a block
+                    // (right behind the wait above), park it two steps before it is needed
+                    const int sib = step & (EBLK / G - 1); // step within its block
+                    const int blk1 = step / (EBLK / G) + 1;
+                    if (sib == 0 && blk1 * EBLK < nent) fetch_block(blk1, r0, r1);
+                    if (sib == EBLK / G - 2 && blk1 * EBLK < nent) park_block(blk1, r0, r1);
 
                     STAMP(ts1);
                     // ---- compute: z = p.q (calc_z), err = r - z (prepare_for_sg_update) ----
-                    float z = o.x * g.x + o.y * g.y + o.z * g.z + o.w * g.w;
-                    z = group_sum<LANES>(z);
+                    // (written on float pairs: one v_pk_* instruction per two factors)
+                    f2 o01 = {o.x, o.y}, o23 = {o.z, o.w}, g01 = {g.x, g.y}, g23 = {g.z, g.w};
+                    const f2 zz = o01 * g01 + o23 * g23;
+                    const float z = group_sum<LANES>(zz.x + zz.y);
                     const float err = act ? rating - z : 0.0f;
                     tsum += err * err;
 
@@ -213,28 +264,45 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     const float eta_g = eta * __builtin_amdgcn_rsqf(slot1 ? gg.y : gg.x);
                     float so = 0.0f, sg = 0.0f;
                     if (upd && act) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float ov = o[j], gv = g[j];
-                            const float go = lam_o * ov - err * gv; // both use the OLD values
-                            const float gq = lam_g * gv - err * ov;
-                            so += go * go;
-                            sg += gq * gq;
-                            o[j] = ov - eta_o * go;
-                            g[j] = gv - eta_g * gq;
-                        }
+                        // both gradients use the OLD values of the other side
+                        const f2 go01 = lam_o * o01 - err * g01, go23 = lam_o * o23 - err * g23;
+                        const f2 gq01 = lam_g * g01 - err * o01, gq23 = lam_g * g23 - err * o23;
+                        const f2 so2 = go01 * go01 + go23 * go23, sg2 = gq01 * gq01 + gq23 * gq23;
+                        so = so2.x + so2.y;
+                        sg = sg2.x + sg2.y;
+                        o01 -= eta_o * go01;
+                        o23 -= eta_o * go23;
+                        g01 -= eta_g * gq01;
+                        g23 -= eta_g * gq23;
+                        o = f4{o01.x, o01.y, o23.x, o23.y};
+                        g = f4{g01.x, g01.y, g23.x, g23.y};
                     }
                     // the gathered row goes back first: the time between its load and this store
                     // is the window in which another wave's update of the same row is lost
-                    if (act && lane_ok) *(f4 *)grow = g;
-                    STAMP(ts2);
-                    const float sg0 = group_sum<LANES>(slot1 ? 0.0f : sg);
-                    gg.x = gg.x + sg0 * rk0;
-                    if (!SLOW) {
-                        const float sg1 = group_sum<LANES>(slot1 ? sg : 0.0f);
-                        gg.y = gg.y + sg1 * rk1;
+                    *(f4 *)grow_c = g;
+                    {
+                        const float sg0 = group_sum<LANES>(slot1 ? 0.0f : sg);
+                        gg.x = gg.x + sg0 * rk0;
+                        if (!SLOW) {
+                            const float sg1 = group_sum<LANES>(slot1 ? sg : 0.0f);
+                            gg.y = gg.y + sg1 * rk1;
+                        }
+                        *(f2 *)gacc_c = gg; // every lane of the group writes the same pair
                     }
-                    if (act && lig == 0) *(f2 *)gacc = gg;
+                    // ---- the next step's loads ----
+                    const bool nact = enext.gat >= 0 && step + 1 < nsteps;
+                    grow = (nact && lane_ok ? a.gat_rows + (size_t)enext.gat * ka : a.scratch) + d0;
+                    gacc = nact ? a.gat_acc + (size_t)enext.gat * 2 : a.scratch + SCRATCH_ROW;
+                    gn = ld_row(grow);
+                    ggn = ld_acc(gacc);
+                    const unsigned id1 = enext.own & IDMASK;
+                    if (nact && (enext.own >> 31) && id1 != cur) { // a visit starts at the next step
+                        pf = id1;
+                        if (lane_ok) on = ld_row(a.own_rows + (size_t)id1 * ka + d0);
+                        ogn = ld_acc(a.own_acc + (size_t)id1 * 2);
+                    }
+                    e = enext;
+                    STAMP(ts2);
                     const float so0 = group_sum<LANES>(slot1 ? 0.0f : so);
                     og0 = og0 + so0 * rk0;
                     if (!SLOW) {
@@ -261,10 +329,14 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
     {
         unsigned long long tend;
         STAMP(tend);
+        RSTAMP(rend);
         c_total = tend - tstart;
         if (lane == 0 && a.stamps) {
             unsigned long long *o = a.stamps + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
             o[0] += c_task; o[1] += c_wait; o[2] += c_win; o[3] += c_rest; o[4] += n_steps; o[5] += n_tasks; o[6] += c_total; o[7] += 1;
+            // timeline of the latest launch: start, end, XCC id, steps of every wave
+            unsigned long long *tl = a.stamps + (size_t)65536 * 8 + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+            tl[0] = rstart; tl[1] = rend; tl[2] = (unsigned long long)(xcc_id() & 15) + 1; tl[3] = n_steps;
         }
     }
 #endif

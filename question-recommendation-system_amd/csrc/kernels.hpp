@@ -10,6 +10,8 @@ struct EntryD { uint32_t own; int32_t gat; float r; };
 struct TaskDescD { uint64_t off; uint32_t nsteps; uint32_t pad; };
 
 constexpr int LOSS_SLOTS = 256; // the epoch loss is kept as this many partial sums
+constexpr int SCRATCH_ROW = 256;    // floats of the scratch row (64 lanes x float4)
+constexpr int SCRATCH_FLOATS = SCRATCH_ROW + 2;
 
 // Arguments of one SGD round (= one launch = NS stripe-disjoint blocks).
 struct RoundArgs {
@@ -22,6 +24,8 @@ struct RoundArgs {
     const long long *slot_task_ptr; // ns+1 task offsets of this round
     int *slot_cursor;               // ns ints, zero before the launch
     double *loss;                   // LOSS_SLOTS partial sums of e^2 (scaled units), accumulated
+    float *scratch;                 // SCRATCH_FLOATS floats: a zero row + accumulators {1,1}; where pad
+                                    // entries and lanes past k_a load and store (never changes value)
     float lambda_own, lambda_gat, eta, rk1;
     int ka, slow_only, ns;
     int n_xcc;                      // XCDs that take work

@@ -91,13 +91,14 @@ struct Rat { uint32_t own; uint32_t gat; float r; };
 // Pack one class of visits into tasks whose lane-group lists hold about `target` ratings:
 // longest-processing-time-first into G*ntasks lists, lists of similar load share a task.
 void pack_class(const std::vector<Visit> &visits, size_t vbeg, size_t vend, int G, int target,
-                BlockPack &out)
+                BlockPack &out, long long force_ntasks = 0)
 {
     if (vbeg >= vend) return;
     long long L = 0;
     for (size_t i = vbeg; i < vend; ++i) L += visits[i].len;
     target = std::max<long long>(target, visits[vbeg].len); // visits are sorted, longest first
     long long ntasks = (L + (long long)G * target - 1) / ((long long)G * target);
+    if (force_ntasks > 0) ntasks = force_ntasks;
     if (ntasks < 1) ntasks = 1;
     const long long NG = ntasks * G;
     typedef std::pair<uint32_t, uint32_t> LB; // (load, list)
@@ -142,7 +143,7 @@ void pack_class(const std::vector<Visit> &visits, size_t vbeg, size_t vend, int 
 } // namespace
 
 // Cut one (owner-stripe, gather-stripe) block, given as its visits, into wavefront tasks.
-void pack_visits(std::vector<Visit> &raw, int G, int target, int hot_len, BlockPack &out)
+void pack_visits(std::vector<Visit> &raw, int G, int target, int hot_len, BlockPack &out, int one_task_waves)
 {
     if (raw.empty()) return;
     // A visit (all ratings of one owner row in this block) longer than hot_len is cut into
@@ -171,6 +172,10 @@ void pack_visits(std::vector<Visit> &raw, int G, int target, int hot_len, BlockP
     // Graded task sizes: the first half of the work goes into full-size tasks, then a
     // quarter at half size, ... so the waves that drain the block's queue last are holding
     // short tasks (the launch ends when the slowest wave does).
+    if (one_task_waves > 0) { // experiment: exactly one task per wave of the block's XCD
+        pack_class(visits, 0, visits.size(), G, 8, out, one_task_waves);
+        return;
+    }
     const double frac[4] = {0.5, 0.75, 0.875, 1.0};
     const char *ge = getenv("MFX_GRADES"); // experiment knob: number of size classes (1..4)
     const int grades = ge && *ge ? std::max(1, std::min(4, atoi(ge))) : 4;
@@ -211,6 +216,8 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
     const int NS = p.ns, NB = NS * NS, G = p.groups;
     int target, hot_len;
     plan_sizes(p.nnz, NB, G, cfg, target, hot_len);
+    const char *ot = getenv("MFX_ONE_TASK"); // experiment knob: tasks per wave (0 = graded dynamic tasks)
+    const int one_task = ot && *ot ? atoi(ot) * std::max(1, cfg.waves_per_stripe) : 0;
     std::vector<BlockPack> packs(NB);
     {
         std::vector<int> blocks(NB);
@@ -223,7 +230,7 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
             for (;;) {
                 int idx = next.fetch_add(1);
                 if (idx >= NB) break;
-                pack_visits(block_visits[blocks[idx]], G, target, hot_len, packs[blocks[idx]]);
+                pack_visits(block_visits[blocks[idx]], G, target, hot_len, packs[blocks[idx]], one_task);
             }
         };
         std::vector<std::thread> pool;

@@ -72,7 +72,8 @@ struct Plan {
 // pieces shared by the host builder (build_plan) and the device builder (prep.hip)
 void plan_header(long long nnz, int m, int n, const PlanConfig &cfg, Plan &p);
 void plan_stats_and_maps(const PlanConfig &cfg, Plan &p); // scale from std_dev, id permutations
-void pack_visits(std::vector<Visit> &visits, int G, int target, int hot_len, BlockPack &out);
+void pack_visits(std::vector<Visit> &visits, int G, int target, int hot_len, BlockPack &out,
+                 int one_task_waves = 0);
 void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig &cfg, Plan &p,
                  std::vector<Placement> &places, int threads);
 

@@ -5,6 +5,7 @@
 // `stripes` kernel launches on one HIP stream.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -97,6 +98,7 @@ struct mfx_trainer {
     DevBuf<int> dSlotState; // per round: cursor[ns]
     DevBuf<double> dScalars; // [0..3] scratch for metrics
     DevBuf<double> dLoss;    // LOSS_SLOTS partial sums of the epoch's online loss
+    DevBuf<float> dScratch;  // RoundArgs::scratch
     DevBuf<int> dOmegaP, dOmegaQ, dPmap, dQmap;
     DevBuf<float> oP, oQ, oPG, oQG; // owned factor storage
     float *dP = nullptr, *dQ = nullptr, *dPG = nullptr, *dQG = nullptr;
@@ -310,6 +312,12 @@ static int create_impl(const mfx::Node *R, const void *R_dev, long long nnz, int
         HIP_TRY(t->dScalars.alloc(4));
         HIP_TRY(t->dLoss.alloc(mfx::LOSS_SLOTS));
         HIP_TRY(hipMemset(t->dLoss.p, 0, mfx::LOSS_SLOTS * sizeof(double)));
+        {
+            float scratch[mfx::SCRATCH_FLOATS] = {0.0f};
+            scratch[mfx::SCRATCH_ROW] = scratch[mfx::SCRATCH_ROW + 1] = 1.0f;
+            HIP_TRY(t->dScratch.alloc(mfx::SCRATCH_FLOATS));
+            HIP_TRY(hipMemcpy(t->dScratch.p, scratch, sizeof(scratch), hipMemcpyHostToDevice));
+        }
         HIP_TRY(t->dOmegaP.alloc(m));
         HIP_TRY(t->dOmegaQ.alloc(n));
         HIP_TRY(t->dPmap.alloc(m));
@@ -482,6 +490,7 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
     a.entries = t->dEntries.p;
     a.tasks = t->dTasks.p;
     a.loss = t->dLoss.p;
+    a.scratch = t->dScratch.p;
     a.lambda_own = p.owner_is_q ? t->lambda_q : t->lambda_p;
     a.lambda_gat = p.owner_is_q ? t->lambda_p : t->lambda_q;
     a.eta = t->opt.eta;
@@ -494,7 +503,7 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
 #ifdef MFX_STAMPS
     { // diagnostic build (`make diag`): where do the cycles of a wave go?  MFX_STAMPS_DUMP=1 prints and resets the sums
         static unsigned long long *g_stamps = nullptr;
-        const size_t words = (size_t)65536 * 8;
+        const size_t words = (size_t)65536 * 12; // 8 sums + 4 timeline words per wave
         if (!g_stamps) {
             (void)hipMalloc((void **)&g_stamps, words * sizeof(unsigned long long));
             (void)hipMemset(g_stamps, 0, words * sizeof(unsigned long long));
@@ -505,7 +514,29 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
             (void)hipDeviceSynchronize();
             (void)hipMemcpy(h.data(), g_stamps, words * 8, hipMemcpyDeviceToHost);
             unsigned long long s8[8] = {0};
-            for (size_t i = 0; i < words; ++i) s8[i % 8] += h[i];
+            for (size_t i = 0; i < (size_t)65536 * 8; ++i) s8[i % 8] += h[i];
+            { // timeline of the latest launch, waves of one XCC, on the 100 MHz device clock
+                const unsigned long long *tl = h.data() + (size_t)65536 * 8;
+                std::vector<unsigned long long> st, en;
+                unsigned long long t0 = ~0ull, steps = 0;
+                for (size_t w = 0; w < 65536; ++w)
+                    if (tl[w * 4 + 2] == 1 && tl[w * 4 + 3] > 0) t0 = std::min(t0, tl[w * 4]);
+                for (size_t w = 0; w < 65536; ++w)
+                    if (tl[w * 4 + 2] == 1 && tl[w * 4 + 3] > 0) {
+                        st.push_back(tl[w * 4] - t0);
+                        en.push_back(tl[w * 4 + 1] - t0);
+                        steps += tl[w * 4 + 3];
+                    }
+                if (!st.empty()) {
+                    std::sort(st.begin(), st.end());
+                    std::sort(en.begin(), en.end());
+                    auto q = [](const std::vector<unsigned long long> &v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+                    fprintf(stderr, "timeline XCC0 (latest launch): %zu working waves, %.1f steps each | start p50 %llu p90 %llu max %llu | "
+                                    "end min %llu p10 %llu p50 %llu p90 %llu max %llu (x10 ns after the first wave started)\n",
+                            st.size(), (double)steps / st.size(), q(st, .5), q(st, .9), st.back(), en.front(), q(en, .1), q(en, .5),
+                            q(en, .9), en.back());
+                }
+            }
             fprintf(stderr, "stamps: waves*launches %llu steps %llu tasks %llu | per step: wait %.0f window %.0f rest %.0f cycles | "
                             "per task: fetch+stage %.0f | wave total %.0f cycles per launch\n",
                     s8[7], s8[4], s8[5], (double)s8[1] / s8[4], (double)s8[2] / s8[4], (double)s8[3] / s8[4],
