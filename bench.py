@@ -161,8 +161,9 @@ def main():
         def epoch(slow=False):
             t.epoch(slow_only=slow, stream=stream)
     else:
+        # (replicas that average Q need the same item layout on every rank: the data-independent one)
         opts = pkg.default_options(k=k, lambda_p2=w["lambda_p"], lambda_q2=w["lambda_q"], eta=w["eta"],
-                                   device=local_rank)
+                                   device=local_rank, identity_maps=2 if world > 1 else 0)
         t = pkg.Trainer(None, m, n, opts=opts, device_ptr=R_dev.data_ptr(), nnz=nnz)
         del R_dev
         info = t.info

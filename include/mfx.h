@@ -48,7 +48,8 @@ typedef struct mfx_options {
     int rk_mode;       /* 0: 1/8 for both accumulator slots (SSE build as shipped,
                           mf.cpp:1233-1234); 1: 1/(k_a-8) for slot 1 (mf.cpp:1314-1315) */
     int owner_side;    /* 0 auto (side with fewer rows), 1 users (P), 2 items (Q)      */
-    int identity_maps; /* 1: skip the id permutation (tests)                           */
+    int identity_maps; /* id layout: 0 mass-balanced stripes (default), 1 identity (tests),
+                          2 the reference's shuffle + equal ranges (mf.cpp:1009-1017, 802) */
     int use_stats;     /* 1: take mean / std-dev from the next two fields instead of
                           collect_info (mf.cpp:462-484) -- a problem split over several
                           trainers or ranks must be scaled by ONE common figure        */
@@ -161,6 +162,7 @@ typedef struct mfx_plan_view {
     const void *entries;            /* {uint32 own|boundary<<31, int32 gat(-1 = pad), float r} */
     const void *tasks;              /* {uint64 entry_off, uint32 nsteps, uint32 pad}            */
     const long long *slot_task_ptr; /* stripes*stripes+1, ordered (round, slot)                */
+    const int *p_begin, *q_begin;   /* stripes+1 internal-id boundaries of the user / item stripes */
 } mfx_plan_view;
 int mfx_hostplan_build(const mfx_node *R_host, long long nnz, int m, int n,
                        const mfx_options *opt, mfx_hostplan **out);

@@ -63,7 +63,8 @@ class PlanView(C.Structure):
                 ("avg", C.c_float), ("std_dev", C.c_float), ("scale", C.c_float),
                 ("inv_scale", C.c_float), ("p_map", C.c_void_p), ("q_map", C.c_void_p),
                 ("omega_p", C.c_void_p), ("omega_q", C.c_void_p), ("entries", C.c_void_p),
-                ("tasks", C.c_void_p), ("slot_task_ptr", C.c_void_p)]
+                ("tasks", C.c_void_p), ("slot_task_ptr", C.c_void_p),
+                ("p_begin", C.c_void_p), ("q_begin", C.c_void_p)]
 
 
 _lib = None
@@ -370,6 +371,8 @@ class HostPlan:
         self.entries = arr(v.entries, v.n_entries, ENTRY)
         self.tasks = arr(v.tasks, v.n_tasks, TASK)
         self.slot_task_ptr = arr(v.slot_task_ptr, v.stripes * v.stripes + 1, np.int64)
+        self.p_begin = arr(v.p_begin, v.stripes + 1, np.int32)
+        self.q_begin = arr(v.q_begin, v.stripes + 1, np.int32)
 
     def init_factors(self):
         v = self.view

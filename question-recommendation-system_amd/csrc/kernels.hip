@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     __shared__ u4 ering_all[4][2 * EBLK]; // per wave: a ring of two blocks, 16-byte slots
     u4 *const ering = ering_all[threadIdx.x >> 6];
+    __shared__ int wg_first;
     const int lane = threadIdx.x & 63;
     const int lig = lane % LANES;
     const int grp = lane / LANES;
@@ -120,7 +121,8 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
     // Blocks ("slots") of this round that belong to this wave's XCD: rank, rank+X, ...
     // (xcc_rank comes from a probe launch; an XCD the probe did not see takes no work and
     // the host's cursor check reports the unfinished blocks -- never a silent wrong answer).
-    const int rank = (int)(threadIdx.x >> 6) < a.active_waves ? a.xcc_rank[xcc_id() & 15] : -1;
+    const int rank = a.xcc_rank[xcc_id() & 15];                   // the same for every wave of a workgroup
+    const bool wave_on = (int)(threadIdx.x >> 6) < a.active_waves; // tiny problems run fewer waves
     double lsum = 0.0;
 #ifdef MFX_STAMPS
     unsigned long long tk0 = 0, tk1 = 0, ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
@@ -133,21 +135,50 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
         for (int slot = rank; slot < a.ns; slot += a.n_xcc) {
             const long long tbeg = a.slot_task_ptr[slot];
             const int ntask = (int)(a.slot_task_ptr[slot + 1] - tbeg);
-            for (;;) {
+            // A task costs a chain of dependent misses before its first step: claim (atomic), descriptor,
+            // entries, rows.  Only the first task of a wave pays it in full: while a task runs, its
+            // first three steps claim the NEXT one, read its descriptor and fetch its first block of
+            // entries into registers (nb0/nb1), each one step apart and right behind a wait.
+            auto claim = [&]() { // -> VGPR, lane 0's value is the claimed index
                 int c = 0;
-                STAMP(tk0);
                 if (lane == 0) c = atomicAdd(&a.slot_cursor[slot], 1);
-                c = __builtin_amdgcn_readfirstlane(c);
-                if (c >= ntask) break;
-
-                // the descriptor is the same for every lane: keep it in SGPRs, so that the step loop
-                // below branches on scalars (real branches, no exec-masked loop exits)
+                return c;
+            };
+            auto fetch_first = [&](unsigned long long off, int nsteps_, EntryD &b0, EntryD &b1) {
+                const EntryD *const base = a.entries + off;
+                const int n = nsteps_ * G;
+                b0 = base[lane < n ? lane : n - 1];
+                b1 = base[lane + 64 < n ? lane + 64 : n - 1];
+            };
+            auto uniform_off = [&](const TaskDescD &d) {
+                return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(d.off >> 32)) << 32) |
+                       (unsigned)__builtin_amdgcn_readfirstlane((int)(d.off & 0xFFFFFFFFu));
+            };
+            STAMP(tk0);
+            // The first claim of a launch is made once per workgroup, not once per wave: every wave
+            // of the XCD asks at the same moment, and atomics on one address take ~70 cycles each.
+            __syncthreads(); // (wg_first is reused per slot)
+            if (threadIdx.x == 0) wg_first = atomicAdd(&a.slot_cursor[slot], a.active_waves);
+            __syncthreads();
+            if (!wave_on) continue;
+            int c = __builtin_amdgcn_readfirstlane(wg_first) + (int)(threadIdx.x >> 6);
+            if (c >= ntask) continue;
+            // the descriptor is the same for every lane: keep it in SGPRs, so that the step loop
+            // below branches on scalars (real branches, no exec-masked loop exits)
+            unsigned long long toff;
+            int nsteps;
+            EntryD nb0, nb1;
+            {
                 const TaskDescD td = a.tasks[tbeg + c];
-                const unsigned long long toff =
-                    ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(td.off >> 32)) << 32) |
-                    (unsigned)__builtin_amdgcn_readfirstlane((int)(td.off & 0xFFFFFFFFu));
-                const EntryD *ep = a.entries + toff + grp;
-                const int nsteps = __builtin_amdgcn_readfirstlane((int)td.nsteps);
+                toff = uniform_off(td);
+                nsteps = __builtin_amdgcn_readfirstlane((int)td.nsteps);
+                fetch_first(toff, nsteps, nb0, nb1);
+            }
+            for (;;) {
+                int cn_v = 0, cn = ntask; // the next task: claim in flight / claimed index
+                TaskDescD tdn_v = {0, 0, 0};
+                unsigned long long toff_n = 0;
+                int nsteps_n = 0;
 
                 unsigned cur = NONE;  // owner row held in registers
                 f4 o = zero4;
@@ -186,8 +217,7 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     return EntryD{v.x, (int)v.y, __builtin_bit_cast(float, rbits)};
 #endif
                 };
-                EntryD r0, r1;
-                fetch_block(0, r0, r1);
+                EntryD r0 = nb0, r1 = nb1; // block 0 was fetched while the task before ran
                 park_block(0, r0, r1);
                 EntryD e = entry_of(0);
                 if (e.gat >= 0) { // every list starts with a visit: fetch its owner row now
@@ -243,6 +273,18 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     // re-waits with vmcnt(0) at later uses of these registers, i.e. behind the
                     // stores below, which costs a full store round trip per step.
                     asm volatile("" : "+v"(g.x), "+v"(g.y), "+v"(g.z), "+v"(g.w), "+v"(gg.x), "+v"(gg.y));
+                    if (step < 3) { // the next task, one dependent access per step (scalar branches)
+                        if (step == 0) {
+                            cn_v = claim();
+                        } else if (step == 1) {
+                            cn = __builtin_amdgcn_readfirstlane(cn_v);
+                            if (cn < ntask) tdn_v = a.tasks[tbeg + cn];
+                        } else if (cn < ntask) {
+                            toff_n = uniform_off(tdn_v);
+                            nsteps_n = __builtin_amdgcn_readfirstlane((int)tdn_v.nsteps);
+                            fetch_first(toff_n, nsteps_n, nb0, nb1);
+                        }
+                    }
                     // block bookkeeping, on scalars: fetch the next block at the start of a block
                     // (right behind the wait above), park it two steps before it is needed
                     const int sib = step & (EBLK / G - 1); // step within its block
@@ -322,6 +364,21 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     if (lig == 0) *(f2 *)(a.own_acc + (size_t)cur * 2) = f2{og0, og1};
                 }
                 if (lig == 0) lsum += (double)tsum;
+                // a task of fewer than three steps has not finished the hand-over: do the rest now
+                STAMP(tk0);
+                if (nsteps < 2) {
+                    cn = __builtin_amdgcn_readfirstlane(cn_v);
+                    if (cn < ntask) tdn_v = a.tasks[tbeg + cn];
+                }
+                if (nsteps < 3 && cn < ntask) {
+                    toff_n = uniform_off(tdn_v);
+                    nsteps_n = __builtin_amdgcn_readfirstlane((int)tdn_v.nsteps);
+                    fetch_first(toff_n, nsteps_n, nb0, nb1);
+                }
+                if (cn >= ntask) break;
+                c = cn;
+                toff = toff_n;
+                nsteps = nsteps_n;
             }
         }
 

@@ -216,8 +216,15 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
     const int NS = p.ns, NB = NS * NS, G = p.groups;
     int target, hot_len;
     plan_sizes(p.nnz, NB, G, cfg, target, hot_len);
-    const char *ot = getenv("MFX_ONE_TASK"); // experiment knob: tasks per wave (0 = graded dynamic tasks)
-    const int one_task = ot && *ot ? atoi(ot) * std::max(1, cfg.waves_per_stripe) : 0;
+    // Tasks per wave.  A block is cut into (tasks per wave) x (waves of its XCD) tasks of equal load
+    // (longest-first packing), handed out through the block's cursor.  One task per wave when a wave's
+    // share of the launch is short -- every hand-over costs a chain of misses -- and two when it is long,
+    // so that the waves that run ahead take up the slack (measured: profiles/experiments/r01_task_sweep*.log).
+    // MFX_ONE_TASK=0 selects the older graded sizes (T, T/2, T/4, T/8 from task_steps).
+    const long long per_wave = p.nnz / ((long long)NB * G * std::max(1, cfg.waves_per_stripe));
+    const char *ot = getenv("MFX_ONE_TASK");
+    const int tasks_per_wave = ot && *ot ? atoi(ot) : cfg.task_steps > 0 ? 0 : per_wave < 160 ? 1 : 2;
+    const int one_task = tasks_per_wave * std::max(1, cfg.waves_per_stripe);
     std::vector<BlockPack> packs(NB);
     {
         std::vector<int> blocks(NB);
@@ -288,20 +295,103 @@ void plan_header(long long nnz, int m, int n, const PlanConfig &cfg, Plan &p)
     if ((long long)p.ns * p.ns > 65535) throw std::invalid_argument("too many stripes");
 }
 
-void plan_stats_and_maps(const PlanConfig &cfg, Plan &p)
+void plan_scale(Plan &p)
 {
     p.scale = std::max((float)1e-4, p.std_dev); // reference mf/mf.cpp:2999
     p.inv_scale = (float)1.0 / p.scale;         // reference mf/mf.cpp:3010
-    if (cfg.identity_maps) {
+}
+
+namespace {
+
+void equal_ranges(int size, int ns, std::vector<int> &begin)
+{
+    const int seg = (size + ns - 1) / ns; // reference seg_p / seg_q, mf.cpp:802-803
+    begin.resize(ns + 1);
+    for (int s = 0; s <= ns; ++s) begin[s] = (int)std::min<long long>((long long)s * seg, size);
+}
+
+// Stripes of (nearly) equal rating mass instead of equal row count.  The reference shuffles the
+// ids (gen_random_map) and cuts equal ranges, which balances its grid only statistically; one
+// row that holds a few per cent of all ratings (a Zipf head) then makes its stripe, and every
+// block of it, that much heavier -- and a round takes as long as its heaviest block.  Here the few
+// heavy rows (more than 1/16 of a stripe's share) are dealt out longest-first, and the others,
+// taken in the reference's shuffled order, are cut where the cumulative mass reaches each
+// stripe's share.
+void balanced_map(int size, int ns, const int *cnt, std::vector<int> &map, std::vector<int> &begin,
+                  std::vector<int> &at)
+{
+    std::vector<int> shuffled;
+    gen_random_map(size, shuffled); // original id -> position in the reference's order
+    std::vector<int> order(size);   // position -> original id
+    for (int i = 0; i < size; ++i) order[shuffled[i]] = i;
+    long long total = 0;
+    for (int i = 0; i < size; ++i) total += cnt[i];
+    const long long heavy_min = std::max<long long>(2, total / ((long long)ns * 16));
+    std::vector<int> heavy;
+    for (int i = 0; i < size; ++i)
+        if (cnt[i] >= heavy_min) heavy.push_back(i);
+    std::stable_sort(heavy.begin(), heavy.end(), [&](int a, int b) { return cnt[a] > cnt[b]; });
+    std::vector<long long> load(ns, 0);
+    std::vector<std::vector<int>> heavy_of(ns);
+    std::vector<char> is_heavy(size, 0);
+    for (int i : heavy) is_heavy[i] = 1;
+    for (int i : heavy) {
+        int best = 0;
+        for (int s = 1; s < ns; ++s)
+            if (load[s] < load[best]) best = s;
+        heavy_of[best].push_back(i);
+        load[best] += cnt[i];
+    }
+    map.assign(size, -1);
+    begin.assign(ns + 1, 0);
+    int next_id = 0, pos = 0;
+    long long light_done = 0, light_want = 0; // cumulative light mass: placed / wanted up to this stripe
+    for (int s = 0; s < ns; ++s) {
+        begin[s] = next_id;
+        for (int i : heavy_of[s]) map[i] = next_id++;
+        light_want += (total * (s + 1)) / ns - (total * s) / ns - load[s];
+        while (pos < size) {
+            const int i = order[pos];
+            if (is_heavy[i]) { ++pos; continue; } // placed with its stripe
+            if (s < ns - 1 && light_done >= light_want && cnt[i] > 0) break;
+            map[i] = next_id++;
+            light_done += cnt[i];
+            ++pos;
+        }
+    }
+    begin[ns] = next_id;
+    at.resize(size);
+    for (int i = 0; i < size; ++i) at[shuffled[i]] = map[i];
+}
+
+} // namespace
+
+void plan_maps(const PlanConfig &cfg, Plan &p, const int *cnt_p, const int *cnt_q)
+{
+    p.p_at.clear();
+    p.q_at.clear();
+    if (cfg.map_mode == 1) {
         p.p_map.resize(p.m);
         p.q_map.resize(p.n);
         for (int i = 0; i < p.m; ++i) p.p_map[i] = i;
         for (int i = 0; i < p.n; ++i) p.q_map[i] = i;
-    } else {
+        equal_ranges(p.m, p.ns, p.p_begin);
+        equal_ranges(p.n, p.ns, p.q_begin);
+    } else if (cfg.map_mode == 2) {
         std::thread tq([&] { gen_random_map(p.n, p.q_map); });
         gen_random_map(p.m, p.p_map);
         tq.join();
+        equal_ranges(p.m, p.ns, p.p_begin);
+        equal_ranges(p.n, p.ns, p.q_begin);
+    } else {
+        std::thread tq([&] { balanced_map(p.n, p.ns, cnt_q, p.q_map, p.q_begin, p.q_at); });
+        balanced_map(p.m, p.ns, cnt_p, p.p_map, p.p_begin, p.p_at);
+        tq.join();
     }
+    p.omega_p.assign(p.m, 0); // omega, mf.cpp:815-816
+    p.omega_q.assign(p.n, 0);
+    for (int i = 0; i < p.m; ++i) p.omega_p[p.p_map[i]] = cnt_p[i];
+    for (int i = 0; i < p.n; ++i) p.omega_q[p.q_map[i]] = cnt_q[i];
 }
 
 void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cfg, Plan &p)
@@ -316,20 +406,23 @@ void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cf
     } else {
         collect_info(R, nnz, threads, p.avg, p.std_dev);
     }
-    plan_stats_and_maps(cfg, p);
+    plan_scale(p);
 
-    // validate ids, relabel (shuffle_problem, mf.cpp:775-791), scale (mf.cpp:517-527),
-    // count rows (omega, mf.cpp:815-816) and bucket by block
+    // validate ids and count the ratings of every row (omega, mf.cpp:815-816)
     const int NS = p.ns;
-    const int n_own = p.owner_is_q ? n : m, n_gat = p.owner_is_q ? m : n;
-    const int seg_own = (n_own + NS - 1) / NS, seg_gat = (n_gat + NS - 1) / NS;
     const int NB = NS * NS;
-    for (long long i = 0; i < nnz; ++i)
+    std::vector<int> cnt_p(m, 0), cnt_q(n, 0);
+    for (long long i = 0; i < nnz; ++i) {
         if (R[i].u < 0 || R[i].u >= m || R[i].v < 0 || R[i].v >= n)
             throw std::invalid_argument("rating with id outside [0,m) x [0,n)");
+        cnt_p[R[i].u]++;
+        cnt_q[R[i].v]++;
+    }
+    plan_maps(cfg, p, cnt_p.data(), cnt_q.data());
 
-    p.omega_p.assign(m, 0);
-    p.omega_q.assign(n, 0);
+    // relabel (shuffle_problem, mf.cpp:775-791), scale (mf.cpp:517-527) and bucket by block
+    const int *own_begin = p.owner_is_q ? p.q_begin.data() : p.p_begin.data();
+    const int *gat_begin = p.owner_is_q ? p.p_begin.data() : p.q_begin.data();
     std::vector<Rat> rat(nnz);
     std::vector<uint16_t> blk(nnz);
     const bool do_scale = p.inv_scale != 1.0f;
@@ -341,15 +434,11 @@ void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cf
             x.gat = p.owner_is_q ? u : v;
             x.r = do_scale ? R[i].r * p.inv_scale : R[i].r;
             rat[i] = x;
-            blk[i] = (uint16_t)((x.own / seg_own) * NS + x.gat / seg_gat);
+            blk[i] = (uint16_t)(stripe_of(own_begin, NS, x.own) * NS + stripe_of(gat_begin, NS, x.gat));
         }
     });
     std::vector<long long> bptr(NB + 1, 0);
-    for (long long i = 0; i < nnz; ++i) {
-        bptr[blk[i] + 1]++;
-        p.omega_p[p.owner_is_q ? rat[i].gat : rat[i].own]++;
-        p.omega_q[p.owner_is_q ? rat[i].own : rat[i].gat]++;
-    }
+    for (long long i = 0; i < nnz; ++i) bptr[blk[i] + 1]++;
     for (int b = 0; b < NB; ++b) bptr[b + 1] += bptr[b];
     std::vector<Rat> sorted(nnz);
     {
@@ -412,33 +501,33 @@ void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cf
 void init_factors(const Plan &p, const int *omega_p_override, const int *omega_q_override,
                   std::vector<float> &P, std::vector<float> &Q, int threads)
 {
-    // One minstd_rand0 stream, P rows then Q rows in internal order, k draws per seen row
-    // scaled by sqrt(1/k); unseen rows NaN; padding zero (reference mf/mf.cpp:952-1007).
+    // One minstd_rand0 stream, P rows then Q rows in the REFERENCE's row order (plan.p_at/q_at),
+    // k draws per seen row scaled by sqrt(1/k); unseen rows NaN; padding zero (mf.cpp:952-1007).
     const int k = p.k, ka = p.ka;
     const float s = (float)std::sqrt(1.0 / k);
     P.assign((size_t)p.m * ka, 0.0f);
     Q.assign((size_t)p.n * ka, 0.0f);
     const int *op = omega_p_override ? omega_p_override : p.omega_p.data();
     const int *oq = omega_q_override ? omega_q_override : p.omega_q.data();
+    auto row_at = [&](long long i) -> long long { // position in the reference's order -> internal row
+        if (i < p.m) return p.p_at.empty() ? i : p.p_at[i];
+        return p.q_at.empty() ? i - p.m : p.q_at[i - p.m];
+    };
     // stream position of every row = k * (seen rows before it)
-    std::vector<uint64_t> pos((size_t)p.m + p.n);
-    uint64_t seen = 0;
-    for (int i = 0; i < p.m; ++i) {
-        pos[i] = seen;
-        seen += op[i] > 0;
-    }
-    for (int i = 0; i < p.n; ++i) {
-        pos[(size_t)p.m + i] = seen;
-        seen += oq[i] > 0;
-    }
     const long long rows = (long long)p.m + p.n;
+    std::vector<uint64_t> pos((size_t)rows);
+    uint64_t seen = 0;
+    for (long long i = 0; i < rows; ++i) {
+        pos[i] = seen;
+        seen += (i < p.m ? op[row_at(i)] : oq[row_at(i)]) > 0;
+    }
     parallel_ranges(rows, threads, [&](long long b, long long e, int) {
         Minstd0 gen(Minstd0::jump(1u, pos[b] * (uint64_t)k));
         for (long long i = b; i < e; ++i) {
-            bool isP = i < p.m;
-            long long row = isP ? i : i - p.m;
+            const bool isP = i < p.m;
+            const long long row = row_at(i);
             float *dst = (isP ? P.data() : Q.data()) + row * ka;
-            bool seen_row = isP ? op[row] > 0 : oq[row] > 0;
+            const bool seen_row = (isP ? op[row] : oq[row]) > 0;
             if (seen_row)
                 for (int d = 0; d < k; ++d) dst[d] = (float)(gen.unit() * s);
             else

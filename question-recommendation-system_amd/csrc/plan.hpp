@@ -46,7 +46,7 @@ struct PlanConfig {
     int lanes = 2;            // lanes per rating (power of two)
     int task_steps = 0;       // 0 = auto
     int owner_side = 0;       // 0 auto, 1 users, 2 items
-    bool identity_maps = false;
+    int map_mode = 0;         // 0 mass-balanced stripes, 1 identity, 2 the reference's shuffle (equal-count stripes)
     bool use_stats = false;   // take avg/std from below instead of collect_info
     float stats_avg = 0, stats_std = 0;
     int waves_per_stripe = 256; // for auto task sizing
@@ -60,6 +60,11 @@ struct Plan {
     bool owner_is_q = true;
     int ns = 8, lanes = 2, groups = 32;
     std::vector<int> p_map, q_map;       // original id -> internal id
+    std::vector<int> p_begin, q_begin;   // ns+1 internal-id boundaries of the user / item stripes
+    // Internal row that sits at position i of the REFERENCE's row order (its shuffled ids,
+    // mf.cpp:1009-1017).  init_model draws the factors in that order, so every original id starts
+    // from the reference's values whatever the layout.  Empty = the layout is that order.
+    std::vector<int> p_at, q_at;
     std::vector<int> omega_p, omega_q;   // ratings per internal row
     std::vector<Entry> entries;
     std::vector<TaskDesc> tasks;
@@ -71,7 +76,23 @@ struct Plan {
 
 // pieces shared by the host builder (build_plan) and the device builder (prep.hip)
 void plan_header(long long nnz, int m, int n, const PlanConfig &cfg, Plan &p);
-void plan_stats_and_maps(const PlanConfig &cfg, Plan &p); // scale from std_dev, id permutations
+void plan_scale(Plan &p);                                  // scale from std_dev
+// id permutations and stripe boundaries; cnt_* = ratings per ORIGINAL id (needed for map_mode 0);
+// also fills omega_p / omega_q (ratings per internal row)
+void plan_maps(const PlanConfig &cfg, Plan &p, const int *cnt_p, const int *cnt_q);
+// stripe of an internal id: largest s with begin[s] <= id
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline int stripe_of(const int *begin, int ns, unsigned id)
+{
+    int lo = 0, hi = ns; // begin[lo] <= id < begin[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((unsigned)begin[mid] <= id) lo = mid; else hi = mid;
+    }
+    return lo;
+}
 void pack_visits(std::vector<Visit> &visits, int G, int target, int hot_len, BlockPack &out,
                  int one_task_waves = 0);
 void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig &cfg, Plan &p,

@@ -54,9 +54,10 @@ template <class T> struct Buf {
     }
 };
 
-// sum and sum of squares in double + id range check (collect_info, mf.cpp:462-484)
+// sum and sum of squares in double + id range check (collect_info, mf.cpp:462-484), and the
+// ratings of every row by ORIGINAL id (omega, mf.cpp:815-816; plan_maps balances the stripes with them)
 __global__ __launch_bounds__(256) void stats_kernel(const Node *R, long long nnz, int m, int n,
-                                                    double *sums, int *bad)
+                                                    double *sums, int *bad, int *cnt_p, int *cnt_q)
 {
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nth = (long long)gridDim.x * blockDim.x;
@@ -66,7 +67,12 @@ __global__ __launch_bounds__(256) void stats_kernel(const Node *R, long long nnz
         const Node x = R[i];
         a += (double)x.r;
         q += (double)x.r * x.r;
-        b |= (x.u < 0) | (x.u >= m) | (x.v < 0) | (x.v >= n);
+        const int out = (x.u < 0) | (x.u >= m) | (x.v < 0) | (x.v >= n);
+        b |= out;
+        if (!out) {
+            atomicAdd(&cnt_p[x.u], 1);
+            atomicAdd(&cnt_q[x.v], 1);
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -81,21 +87,24 @@ __global__ __launch_bounds__(256) void stats_kernel(const Node *R, long long nnz
 }
 
 // relabel, scale, count rows, build the sort key (block | owner id | gathered id)
+// bounds: own_begin[ns+1] then gat_begin[ns+1] (internal-id boundaries of the stripes)
 __global__ __launch_bounds__(256) void key_build(const Node *R, long long nnz, const int *p_map,
                                                  const int *q_map, int owner_is_q, float inv_scale,
-                                                 int do_scale, int seg_own, int seg_gat, int ns,
-                                                 int *omega_p, int *omega_q,
+                                                 int do_scale, const int *bounds, int ns,
                                                  unsigned long long *keys, float *vals)
 {
+    __shared__ int sb[2 * 257];
+    for (int i = threadIdx.x; i < 2 * (ns + 1); i += blockDim.x) sb[i] = bounds[i];
+    __syncthreads();
+    const int *own_begin = sb, *gat_begin = sb + ns + 1;
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nth = (long long)gridDim.x * blockDim.x;
     for (long long i = tid; i < nnz; i += nth) {
         const Node x = R[i];
         const unsigned u = (unsigned)p_map[x.u], v = (unsigned)q_map[x.v];
-        atomicAdd(&omega_p[u], 1);
-        atomicAdd(&omega_q[v], 1);
         const unsigned own = owner_is_q ? v : u, gat = owner_is_q ? u : v;
-        const unsigned long long blk = (unsigned long long)(own / (unsigned)seg_own) * ns + gat / (unsigned)seg_gat;
+        const unsigned long long blk =
+            (unsigned long long)stripe_of(own_begin, ns, own) * ns + stripe_of(gat_begin, ns, gat);
         keys[i] = (blk << (2 * ID_BITS)) | ((unsigned long long)own << ID_BITS) | gat;
         vals[i] = do_scale ? x.r * inv_scale : x.r;
     }
@@ -138,12 +147,22 @@ __global__ __launch_bounds__(256) void emit_entries(const Placement *pl, long lo
 // can be entered anywhere: x_{i+j} = 16807^j x_i, so every row starts from its own stream position
 // (k times the number of seen rows before it, an exclusive scan) and the result is bit-identical.
 
+// i = position in the reference's row order (P rows, then Q rows); at = position -> internal row (null: identity)
+__device__ __forceinline__ long long row_at(long long i, int m, const int *p_at, const int *q_at)
+{
+    if (i < m) return p_at ? p_at[i] : i;
+    return q_at ? q_at[i - m] : i - m;
+}
+
 __global__ __launch_bounds__(256) void seen_flags(const int *omega_p, int m, const int *omega_q, int n,
-                                                  unsigned long long *flag)
+                                                  const int *p_at, const int *q_at, unsigned long long *flag)
 {
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nth = (long long)gridDim.x * blockDim.x, rows = (long long)m + n;
-    for (long long i = tid; i < rows; i += nth) flag[i] = (i < m ? omega_p[i] : omega_q[i - m]) > 0 ? 1ull : 0ull;
+    for (long long i = tid; i < rows; i += nth) {
+        const long long row = row_at(i, m, p_at, q_at);
+        flag[i] = (i < m ? omega_p[row] : omega_q[row]) > 0 ? 1ull : 0ull;
+    }
 }
 
 __device__ __forceinline__ unsigned minstd_mul(unsigned a, unsigned b)
@@ -152,14 +171,14 @@ __device__ __forceinline__ unsigned minstd_mul(unsigned a, unsigned b)
 }
 
 __global__ __launch_bounds__(256) void init_rows(const unsigned long long *seen_before, const int *omega_p, int m,
-                                                 const int *omega_q, int n, int k, int ka, float scale,
-                                                 float *P, float *Q)
+                                                 const int *omega_q, int n, const int *p_at, const int *q_at,
+                                                 int k, int ka, float scale, float *P, float *Q)
 {
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nth = (long long)gridDim.x * blockDim.x, rows = (long long)m + n;
     for (long long i = tid; i < rows; i += nth) {
         const bool isP = i < m;
-        const long long row = isP ? i : i - m;
+        const long long row = row_at(i, m, p_at, q_at);
         float *dst = (isP ? P : Q) + row * ka;
         const bool seen = (isP ? omega_p[row] : omega_q[row]) > 0;
         if (seen) {
@@ -188,14 +207,24 @@ int grid_of(long long n, int cu) { return (int)std::max<long long>(1, std::min<l
 
 } // namespace
 
-void init_factors_device(const int *d_omega_p, int m, const int *d_omega_q, int n, int k, int ka, int cu_count,
-                         hipStream_t s, float *dP, float *dQ)
+void init_factors_device(const int *d_omega_p, int m, const int *d_omega_q, int n, const int *p_at_host,
+                         const int *q_at_host, int k, int ka, int cu_count, hipStream_t s, float *dP, float *dQ)
 {
     const long long rows = (long long)m + n;
     Buf<unsigned long long> dFlag, dScan;
+    Buf<int> dPat, dQat;
+    if (p_at_host) {
+        dPat.alloc(m);
+        PREP_TRY(hipMemcpyAsync(dPat.p, p_at_host, (size_t)m * 4, hipMemcpyHostToDevice, s));
+    }
+    if (q_at_host) {
+        dQat.alloc(n);
+        PREP_TRY(hipMemcpyAsync(dQat.p, q_at_host, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    }
     dFlag.alloc((size_t)rows);
     dScan.alloc((size_t)rows);
-    hipLaunchKernelGGL(seen_flags, dim3(grid_of(rows, cu_count)), dim3(256), 0, s, d_omega_p, m, d_omega_q, n, dFlag.p);
+    hipLaunchKernelGGL(seen_flags, dim3(grid_of(rows, cu_count)), dim3(256), 0, s, d_omega_p, m, d_omega_q, n, dPat.p,
+                       dQat.p, dFlag.p);
     size_t tmp_bytes = 0;
     PREP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, dFlag.p, dScan.p, (int)rows, s));
     Buf<char> dTmp;
@@ -203,7 +232,7 @@ void init_factors_device(const int *d_omega_p, int m, const int *d_omega_q, int 
     PREP_TRY(hipcub::DeviceScan::ExclusiveSum(dTmp.p, tmp_bytes, dFlag.p, dScan.p, (int)rows, s));
     const float scale = (float)std::sqrt(1.0 / k); // mf.cpp:971
     hipLaunchKernelGGL(init_rows, dim3(grid_of(rows, cu_count)), dim3(256), 0, s, dScan.p, d_omega_p, m, d_omega_q,
-                       n, k, ka, scale, dP, dQ);
+                       n, dPat.p, dQat.p, k, ka, scale, dP, dQ);
     PREP_TRY(hipGetLastError());
     PREP_TRY(hipStreamSynchronize(s));
 }
@@ -228,11 +257,20 @@ void build_plan_device(const void *dR_v, long long nnz, int m, int n, const Plan
     dBad.alloc(1);
     PREP_TRY(hipMemsetAsync(dSums.p, 0, 2 * sizeof(double), s));
     PREP_TRY(hipMemsetAsync(dBad.p, 0, sizeof(int), s));
-    hipLaunchKernelGGL(stats_kernel, dim3(grid_of(nnz, cu_count)), dim3(256), 0, s, dR, nnz, m, n, dSums.p, dBad.p);
+    Buf<int> dCntP, dCntQ;
+    dCntP.alloc(m);
+    dCntQ.alloc(n);
+    PREP_TRY(hipMemsetAsync(dCntP.p, 0, (size_t)m * 4, s));
+    PREP_TRY(hipMemsetAsync(dCntQ.p, 0, (size_t)n * 4, s));
+    hipLaunchKernelGGL(stats_kernel, dim3(grid_of(nnz, cu_count)), dim3(256), 0, s, dR, nnz, m, n, dSums.p, dBad.p,
+                       dCntP.p, dCntQ.p);
     double sums[2];
     int bad = 0;
+    std::vector<int> cnt_p(m), cnt_q(n);
     PREP_TRY(hipMemcpyAsync(sums, dSums.p, sizeof(sums), hipMemcpyDeviceToHost, s));
     PREP_TRY(hipMemcpyAsync(&bad, dBad.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    PREP_TRY(hipMemcpyAsync(cnt_p.data(), dCntP.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+    PREP_TRY(hipMemcpyAsync(cnt_q.data(), dCntQ.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     PREP_TRY(hipStreamSynchronize(s));
     if (bad) throw std::invalid_argument("rating with id outside [0,m) x [0,n)");
     if (cfg.use_stats) {
@@ -243,29 +281,30 @@ void build_plan_device(const void *dR_v, long long nnz, int m, int n, const Plan
         p.avg = (float)ex;
         p.std_dev = (float)std::sqrt(ex2 - ex * ex);
     }
-    plan_stats_and_maps(cfg, p); // scale, inv_scale, p_map, q_map (host: the glibc-compatible shuffle is serial)
+    plan_scale(p);
+    // id maps, stripe boundaries, omega (host: the glibc-compatible shuffle is serial)
+    plan_maps(cfg, p, cnt_p.data(), cnt_q.data());
 
     // 2. keys
-    Buf<int> dPmap, dQmap, dOmegaP, dOmegaQ;
+    Buf<int> dPmap, dQmap, dBounds;
     dPmap.alloc(m);
     dQmap.alloc(n);
-    dOmegaP.alloc(m);
-    dOmegaQ.alloc(n);
+    dBounds.alloc(2 * (NS + 1));
     PREP_TRY(hipMemcpyAsync(dPmap.p, p.p_map.data(), (size_t)m * 4, hipMemcpyHostToDevice, s));
     PREP_TRY(hipMemcpyAsync(dQmap.p, p.q_map.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-    PREP_TRY(hipMemsetAsync(dOmegaP.p, 0, (size_t)m * 4, s));
-    PREP_TRY(hipMemsetAsync(dOmegaQ.p, 0, (size_t)n * 4, s));
+    {
+        const std::vector<int> &ob = p.owner_is_q ? p.q_begin : p.p_begin, &gb = p.owner_is_q ? p.p_begin : p.q_begin;
+        PREP_TRY(hipMemcpyAsync(dBounds.p, ob.data(), (size_t)(NS + 1) * 4, hipMemcpyHostToDevice, s));
+        PREP_TRY(hipMemcpyAsync(dBounds.p + NS + 1, gb.data(), (size_t)(NS + 1) * 4, hipMemcpyHostToDevice, s));
+    }
     Buf<unsigned long long> dKeyA, dKeyB;
     Buf<float> dValA, dValB;
     dKeyA.alloc(nnz);
     dKeyB.alloc(nnz);
     dValA.alloc(nnz);
     dValB.alloc(nnz);
-    const int n_own = p.owner_is_q ? n : m, n_gat = p.owner_is_q ? m : n;
-    const int seg_own = (n_own + NS - 1) / NS, seg_gat = (n_gat + NS - 1) / NS;
     hipLaunchKernelGGL(key_build, dim3(grid_of(nnz, cu_count)), dim3(256), 0, s, dR, nnz, dPmap.p, dQmap.p,
-                       p.owner_is_q ? 1 : 0, p.inv_scale, p.inv_scale != 1.0f ? 1 : 0, seg_own, seg_gat, NS,
-                       dOmegaP.p, dOmegaQ.p, dKeyA.p, dValA.p);
+                       p.owner_is_q ? 1 : 0, p.inv_scale, p.inv_scale != 1.0f ? 1 : 0, dBounds.p, NS, dKeyA.p, dValA.p);
 
     // 3. sort by (block, owner, gathered); stable, so equal pairs keep their input order
     int blk_bits = 1;
@@ -295,10 +334,6 @@ void build_plan_device(const void *dR_v, long long nnz, int m, int n, const Plan
     std::vector<int> run_len((size_t)runs);
     PREP_TRY(hipMemcpyAsync(run_key.data(), dKeyA.p, (size_t)runs * 8, hipMemcpyDeviceToHost, s));
     PREP_TRY(hipMemcpyAsync(run_len.data(), dRunLen.p, (size_t)runs * 4, hipMemcpyDeviceToHost, s));
-    p.omega_p.resize(m);
-    p.omega_q.resize(n);
-    PREP_TRY(hipMemcpyAsync(p.omega_p.data(), dOmegaP.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
-    PREP_TRY(hipMemcpyAsync(p.omega_q.data(), dOmegaQ.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     PREP_TRY(hipStreamSynchronize(s));
 
     // 5. host: visits per block, packing into tasks (same code as the host builder)

@@ -18,8 +18,9 @@ void build_plan_device(const void *dR, long long nnz, int m, int n, const PlanCo
                        hipStream_t s, Plan &p, EntryD **d_entries);
 
 // init_model (reference mf/mf.cpp:952-1007) on the device, bit-identical to the host's init_factors:
-// row counts (internal order) already in HBM, factors written with stride ka.
-void init_factors_device(const int *d_omega_p, int m, const int *d_omega_q, int n, int k, int ka, int cu_count,
-                         hipStream_t s, float *dP, float *dQ);
+// row counts (internal order) already in HBM, factors written with stride ka.  p_at/q_at (host, may be
+// null = identity): internal row at each position of the reference's row order (Plan::p_at).
+void init_factors_device(const int *d_omega_p, int m, const int *d_omega_q, int n, const int *p_at_host,
+                         const int *q_at_host, int k, int ka, int cu_count, hipStream_t s, float *dP, float *dQ);
 
 } // namespace mfx

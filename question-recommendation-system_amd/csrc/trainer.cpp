@@ -180,7 +180,7 @@ static mfx::PlanConfig plan_config(const mfx_options &opt, int stripes, int wgs_
     cfg.lanes = mfx::lanes_for(mfx::k_aligned(opt.k));
     cfg.task_steps = opt.task_steps > 0 ? opt.task_steps : env_int("MFX_TASK_STEPS", 0);
     cfg.owner_side = opt.owner_side;
-    cfg.identity_maps = opt.identity_maps != 0;
+    cfg.map_mode = env_int("MFX_MAP_MODE", opt.identity_maps); // 0 mass-balanced stripes, 1 identity, 2 the reference's shuffle
     cfg.use_stats = opt.use_stats != 0;
     cfg.stats_avg = opt.stats_avg;
     cfg.stats_std = opt.stats_std;
@@ -429,7 +429,8 @@ int mfx_trainer_init_model_counts(mfx_trainer *t, const int *omega_p, const int 
         if (omega_q) HIP_TRY(hipMemcpy(t->dOmegaQ.p, oq.data(), (size_t)p.n * 4, hipMemcpyHostToDevice));
         if (env_int("MFX_HOST_INIT", 0) == 0) {
             // the reference's single minstd_rand0 stream, entered per row by skip-ahead (prep.hip)
-            mfx::init_factors_device(t->dOmegaP.p, p.m, t->dOmegaQ.p, p.n, p.k, p.ka, t->cu_count, t->stream,
+            mfx::init_factors_device(t->dOmegaP.p, p.m, t->dOmegaQ.p, p.n, p.p_at.empty() ? nullptr : p.p_at.data(),
+                                     p.q_at.empty() ? nullptr : p.q_at.data(), p.k, p.ka, t->cu_count, t->stream,
                                      t->dP, t->dQ);
         } else {
             std::vector<float> P, Q;
@@ -515,26 +516,26 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
             (void)hipMemcpy(h.data(), g_stamps, words * 8, hipMemcpyDeviceToHost);
             unsigned long long s8[8] = {0};
             for (size_t i = 0; i < (size_t)65536 * 8; ++i) s8[i % 8] += h[i];
-            { // timeline of the latest launch, waves of one XCC, on the 100 MHz device clock
+            { // timeline of the latest launch on the 100 MHz device clock, per XCC
                 const unsigned long long *tl = h.data() + (size_t)65536 * 8;
-                std::vector<unsigned long long> st, en;
-                unsigned long long t0 = ~0ull, steps = 0;
+                unsigned long long t0 = ~0ull;
                 for (size_t w = 0; w < 65536; ++w)
-                    if (tl[w * 4 + 2] == 1 && tl[w * 4 + 3] > 0) t0 = std::min(t0, tl[w * 4]);
-                for (size_t w = 0; w < 65536; ++w)
-                    if (tl[w * 4 + 2] == 1 && tl[w * 4 + 3] > 0) {
-                        st.push_back(tl[w * 4] - t0);
-                        en.push_back(tl[w * 4 + 1] - t0);
-                        steps += tl[w * 4 + 3];
-                    }
-                if (!st.empty()) {
+                    if (tl[w * 4 + 2] && tl[w * 4 + 3] > 0) t0 = std::min(t0, tl[w * 4]);
+                for (unsigned long long x = 1; x <= 16; ++x) {
+                    std::vector<unsigned long long> st, en;
+                    unsigned long long steps = 0;
+                    for (size_t w = 0; w < 65536; ++w)
+                        if (tl[w * 4 + 2] == x && tl[w * 4 + 3] > 0) {
+                            st.push_back(tl[w * 4] - t0);
+                            en.push_back(tl[w * 4 + 1] - t0);
+                            steps += tl[w * 4 + 3];
+                        }
+                    if (st.empty()) continue;
                     std::sort(st.begin(), st.end());
                     std::sort(en.begin(), en.end());
                     auto q = [](const std::vector<unsigned long long> &v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
-                    fprintf(stderr, "timeline XCC0 (latest launch): %zu working waves, %.1f steps each | start p50 %llu p90 %llu max %llu | "
-                                    "end min %llu p10 %llu p50 %llu p90 %llu max %llu (x10 ns after the first wave started)\n",
-                            st.size(), (double)steps / st.size(), q(st, .5), q(st, .9), st.back(), en.front(), q(en, .1), q(en, .5),
-                            q(en, .9), en.back());
+                    fprintf(stderr, "timeline XCC%llu: %zu waves x %.1f steps | start max %llu | end min %llu p10 %llu p50 %llu p90 %llu max %llu (x10 ns)\n",
+                            x - 1, st.size(), (double)steps / st.size(), st.back(), en.front(), q(en, .1), q(en, .5), q(en, .9), en.back());
                 }
             }
             fprintf(stderr, "stamps: waves*launches %llu steps %llu tasks %llu | per step: wait %.0f window %.0f rest %.0f cycles | "
@@ -940,6 +941,8 @@ int mfx_hostplan_view(const mfx_hostplan *h, mfx_plan_view *v)
     v->entries = p.entries.data();
     v->tasks = p.tasks.data();
     v->slot_task_ptr = p.slot_task_ptr.data();
+    v->p_begin = p.p_begin.data();
+    v->q_begin = p.q_begin.data();
     return MFX_OK;
 }
 

@@ -106,7 +106,10 @@ class RotatingTrainer:
             Rs["v"] -= s * self.seg
             if len(Rs) == 0:
                 raise ValueError("rank %d holds no rating for item stripe %d" % (rank, s))
-            opts = pkg.default_options(use_stats=1, stats_avg=float(avg), stats_std=float(std), **opt_kw)
+            # identity_maps=2: the reference's data-independent id layout -- the N trainers of a rank share
+            # one P, so they must all place a user in the same row
+            opts = pkg.default_options(use_stats=1, stats_avg=float(avg), stats_std=float(std),
+                                       **{"identity_maps": 2, **opt_kw})
             self.trainers.append(pkg.Trainer(Rs, m, self.seg, opts=opts))
         i0 = self.trainers[0].info
         self.ka = i0.k_aligned

@@ -28,4 +28,4 @@ for spec in (sys.argv[1:] or ["-"]):
     print("==", spec, flush=True)
     p = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT)], env=env, capture_output=True, text=True, timeout=600)
     out = [l for l in (p.stdout + p.stderr).splitlines() if l.startswith(("stamps", "timeline")) or "ms/epoch" in l]
-    print("\n".join(out[-3:]) if p.returncode == 0 else (p.stdout + p.stderr)[-3000:], flush=True)
+    print("\n".join(out[-10:]) if p.returncode == 0 else (p.stdout + p.stderr)[-3000:], flush=True)

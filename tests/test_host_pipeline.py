@@ -17,11 +17,12 @@ def internal(R, hp, orc):
 def test_maps_stats_counts_init_match_oracle(pkg, orc, shape):
     m, n, nnz, k = shape
     R = pkg.synth_host(5, 0, nnz, m, n)
-    hp = pkg.HostPlan(R, m, n, k=k)
+    hp = pkg.HostPlan(R, m, n, k=k, identity_maps=2)  # 2 = the reference's id layout
     v = hp.view
-    # gen_random_map (mf.cpp:1009-1017)
+    # gen_random_map (mf.cpp:1009-1017), equal ranges (seg_p/seg_q, mf.cpp:802-803)
     assert np.array_equal(hp.p_map, orc.gen_random_map(m))
     assert np.array_equal(hp.q_map, orc.gen_random_map(n))
+    assert np.array_equal(hp.p_begin, np.minimum(np.arange(v.stripes + 1) * -(-m // v.stripes), m))
     # collect_info (mf.cpp:462-484), scale (mf.cpp:2999)
     avg, sd = orc.collect_info(R)
     assert (v.avg, v.std_dev) == (avg, sd)
@@ -58,8 +59,13 @@ def check_plan(pkg, orc, R, m, n, k, **kw):
     assert sptr[0] == 0 and sptr[-1] == len(tasks) and (np.diff(sptr) >= 0).all()
     assert int((tasks["nsteps"].astype(np.int64) * G).sum()) == len(e)
     assert np.array_equal(tasks["off"][1:], np.cumsum(tasks["nsteps"].astype(np.int64) * G)[:-1].astype(np.uint64))
-    n_own, n_gat = (n, m) if v.owner_is_q else (m, n)
-    seg_o, seg_g = -(-n_own // NS), -(-n_gat // NS)
+    own_begin, gat_begin = (hp.q_begin, hp.p_begin) if v.owner_is_q else (hp.p_begin, hp.q_begin)
+    for b, size in ((hp.p_begin, m), (hp.q_begin, n)):  # the stripes tile the id range
+        assert b[0] == 0 and b[-1] == size and (np.diff(b) >= 0).all()
+    for mp, size in ((hp.p_map, m), (hp.q_map, n)):     # the id maps are permutations
+        assert np.array_equal(np.sort(mp), np.arange(size))
+    stripe_o = lambda ids: np.searchsorted(own_begin, ids, side="right") - 1
+    stripe_g = lambda ids: np.searchsorted(gat_begin, ids, side="right") - 1
     own_all = (e["own"] & 0x7FFFFFFF).astype(np.int64)
     for r in range(NS):
         used_o, used_g = set(), set()
@@ -69,7 +75,7 @@ def check_plan(pkg, orc, R, m, n, k, **kw):
                 continue
             lo = int(tasks["off"][t0]); hi = int(tasks["off"][t1 - 1]) + int(tasks["nsteps"][t1 - 1]) * G
             a = e["gat"][lo:hi] >= 0
-            so = set(np.unique(own_all[lo:hi][a] // seg_o)); sg = set(np.unique(e["gat"][lo:hi][a] // seg_g))
+            so = set(np.unique(stripe_o(own_all[lo:hi][a]))); sg = set(np.unique(stripe_g(e["gat"][lo:hi][a])))
             # a block lives in ONE owner stripe and ONE gathered stripe ...
             assert so == {s} and sg == {(s + r) % NS}
             # ... and the blocks of a round share no stripe (reference mf.cpp:133-141)
@@ -93,6 +99,30 @@ def test_plan_layout_invariants(pkg, orc):
     check_plan(pkg, orc, R, 2500, 1800, 32)
     check_plan(pkg, orc, R, 2500, 1800, 8, stripes=4, task_steps=16)
     check_plan(pkg, orc, R, 2500, 1800, 64, owner_side=1)
+
+
+def test_stripes_are_mass_balanced(pkg, orc):
+    """Default id layout: a row with ~5 % of all ratings must not make its stripe (and the
+    rounds its blocks are in) heavier than the others."""
+    m, n, nnz, NS = 20000, 10000, 2000000, 8
+    R = pkg.synth_host(1, 0, nnz, m, n)
+    assert np.bincount(R["u"]).max() > 0.03 * nnz  # the synthetic head row
+    hp = pkg.HostPlan(R, m, n, k=32)
+    for omega, begin in ((hp.omega_p, hp.p_begin), (hp.omega_q, hp.q_begin)):
+        mass = np.add.reduceat(omega, begin[:-1])
+        assert mass.sum() == nnz and mass.max() < 1.02 * nnz / NS
+    su = np.searchsorted(hp.p_begin, hp.p_map[R["u"]], side="right") - 1
+    sv = np.searchsorted(hp.q_begin, hp.q_map[R["v"]], side="right") - 1
+    B = np.bincount(su * NS + sv, minlength=NS * NS).reshape(NS, NS)
+    rounds = sum(max(B[(s + r) % NS, s] for s in range(NS)) for r in range(NS))
+    assert rounds < 1.05 * nnz / NS  # a round costs its heaviest block
+    for mode in (1, 2):  # the equal-count layouts still work (and are what the oracle pinning uses)
+        check_plan(pkg, orc, R[:50000], m, n, 16, identity_maps=mode)
+    # init_model: every ORIGINAL id starts from the reference's values whatever the layout
+    ref = pkg.HostPlan(R, m, n, k=32, identity_maps=2)
+    (P0, Q0), (P2, Q2) = hp.init_factors(), ref.init_factors()
+    assert np.array_equal(P0[hp.p_map].view(np.uint32), P2[ref.p_map].view(np.uint32))
+    assert np.array_equal(Q0[hp.q_map].view(np.uint32), Q2[ref.q_map].view(np.uint32))
 
 
 def test_plan_edge_cases(pkg, orc):
