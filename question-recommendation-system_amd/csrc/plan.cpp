@@ -223,7 +223,7 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
     // MFX_ONE_TASK=0 selects the older graded sizes (T, T/2, T/4, T/8 from task_steps).
     const long long per_wave = p.nnz / ((long long)NB * G * std::max(1, cfg.waves_per_stripe));
     const char *ot = getenv("MFX_ONE_TASK");
-    const int tasks_per_wave = ot && *ot ? atoi(ot) : cfg.task_steps > 0 ? 0 : per_wave < 160 ? 1 : 2;
+    const int tasks_per_wave = ot && *ot ? atoi(ot) : cfg.task_steps > 0 ? 0 : per_wave < 128 ? 1 : 2;
     const int one_task = tasks_per_wave * std::max(1, cfg.waves_per_stripe);
     std::vector<BlockPack> packs(NB);
     {
