@@ -99,6 +99,9 @@ template <int LANES, bool FULL, bool SLOW>
 __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
 {
     constexpr int G = 64 / LANES;
+    // Order of the memory burst that ends a step (measured per width, profiles/experiments/r01_burst_order.log):
+    // wide rows gain from sending the next step's loads ahead of the accumulator store, narrow ones lose.
+    constexpr bool LOADS_FIRST = LANES >= 16;
     constexpr int EBLK = 128; // entries per block of the entry stream (two per lane); EBLK/G steps
     static_assert(EBLK / G >= 4, "a block of the entry stream must span at least four steps");
     constexpr unsigned NONE = 0xFFFFFFFFu, IDMASK = 0x7FFFFFFFu;
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
     const bool wave_on = (int)(threadIdx.x >> 6) < a.active_waves; // tiny problems run fewer waves
     double lsum = 0.0;
 #ifdef MFX_STAMPS
-    unsigned long long tk0 = 0, tk1 = 0, ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+    unsigned long long tk0 = 0, tk1 = 0, ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, tsb = 0, c_burst = 0;
     unsigned long long c_task = 0, c_wait = 0, c_win = 0, c_rest = 0, n_steps = 0, n_tasks = 0, c_total = 0, tstart = 0;
     unsigned long long rstart = 0, rend = 0;
     STAMP(tstart);
@@ -319,10 +322,23 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                         o = f4{o01.x, o01.y, o23.x, o23.y};
                         g = f4{g01.x, g01.y, g23.x, g23.y};
                     }
-                    // the gathered row goes back first: the time between its load and this store
-                    // is the window in which another wave's update of the same row is lost
-                    *(f4 *)grow_c = g;
-                    {
+                    // ---- one burst of memory operations ----
+                    const bool nact = enext.gat >= 0 && step + 1 < nsteps;
+                    grow = (nact && lane_ok ? a.gat_rows + (size_t)enext.gat * ka : a.scratch) + d0;
+                    gacc = nact ? a.gat_acc + (size_t)enext.gat * 2 : a.scratch + SCRATCH_ROW;
+                    const unsigned id1 = enext.own & IDMASK;
+                    auto owner_prefetch = [&]() {
+                        if (nact && (enext.own >> 31) && id1 != cur) { // a visit starts at the next step
+                            pf = id1;
+                            if (lane_ok) on = ld_row(a.own_rows + (size_t)id1 * ka + d0);
+                            ogn = ld_acc(a.own_acc + (size_t)id1 * 2);
+                        }
+                    };
+                    auto next_loads = [&]() {
+                        gn = ld_row(grow);
+                        ggn = ld_acc(gacc);
+                    };
+                    auto acc_store = [&]() {
                         const float sg0 = group_sum<LANES>(slot1 ? 0.0f : sg);
                         gg.x = gg.x + sg0 * rk0;
                         if (!SLOW) {
@@ -330,18 +346,33 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                             gg.y = gg.y + sg1 * rk1;
                         }
                         *(f2 *)gacc_c = gg; // every lane of the group writes the same pair
-                    }
-                    // ---- the next step's loads ----
-                    const bool nact = enext.gat >= 0 && step + 1 < nsteps;
-                    grow = (nact && lane_ok ? a.gat_rows + (size_t)enext.gat * ka : a.scratch) + d0;
-                    gacc = nact ? a.gat_acc + (size_t)enext.gat * 2 : a.scratch + SCRATCH_ROW;
-                    gn = ld_row(grow);
-                    ggn = ld_acc(gacc);
-                    const unsigned id1 = enext.own & IDMASK;
-                    if (nact && (enext.own >> 31) && id1 != cur) { // a visit starts at the next step
-                        pf = id1;
-                        if (lane_ok) on = ld_row(a.own_rows + (size_t)id1 * ka + d0);
-                        ogn = ld_acc(a.own_acc + (size_t)id1 * 2);
+                    };
+                    STAMP(tsb);
+                    // the gathered row goes back first: the time between its load and this store is the
+                    // window in which another wave's update of the same row is lost
+                    *(f4 *)grow_c = g;
+                    if constexpr (!LOADS_FIRST) {
+                        // accumulator store, then the next step's loads: the wait at the top of the next
+                        // step covers the whole burst
+                        acc_store();
+                        next_loads();
+                        owner_prefetch();
+                    } else {
+                        // The next step's loads go out before the accumulator reductions, and the wait at
+                        // the top of the next step (vmcnt retires in order) leaves the accumulator store
+                        // in flight.  If the next entry of a lane group names the same gathered row (a
+                        // duplicate rating), its load must see this step's accumulators: that wave stores
+                        // first and drains.
+                        const bool again = nact && act && enext.gat == e.gat;
+                        owner_prefetch();
+                        if (__builtin_amdgcn_ballot_w64(again) == 0) {
+                            next_loads();
+                            acc_store();
+                        } else {
+                            acc_store();
+                            next_loads();
+                            __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): both orders leave the same state behind
+                        }
                     }
                     e = enext;
                     STAMP(ts2);
@@ -355,6 +386,7 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
 #ifdef MFX_STAMPS
                     c_wait += ts1 - ts0;
                     c_win += ts2 - ts1;
+                    c_burst += ts2 - tsb;
                     c_rest += ts3 - ts2;
                     n_steps++;
 #endif
@@ -393,7 +425,7 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
             o[0] += c_task; o[1] += c_wait; o[2] += c_win; o[3] += c_rest; o[4] += n_steps; o[5] += n_tasks; o[6] += c_total; o[7] += 1;
             // timeline of the latest launch: start, end, XCC id, steps of every wave
             unsigned long long *tl = a.stamps + (size_t)65536 * 8 + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
-            tl[0] = rstart; tl[1] = rend; tl[2] = (unsigned long long)(xcc_id() & 15) + 1; tl[3] = n_steps;
+            tl[0] = rstart; tl[1] = rend; tl[2] = (unsigned long long)(xcc_id() & 15) + 1; tl[3] = n_steps | (c_burst << 20);
         }
     }
 #endif

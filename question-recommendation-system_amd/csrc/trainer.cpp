@@ -520,22 +520,23 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
                 const unsigned long long *tl = h.data() + (size_t)65536 * 8;
                 unsigned long long t0 = ~0ull;
                 for (size_t w = 0; w < 65536; ++w)
-                    if (tl[w * 4 + 2] && tl[w * 4 + 3] > 0) t0 = std::min(t0, tl[w * 4]);
+                    if (tl[w * 4 + 2] && (tl[w * 4 + 3] & 0xFFFFF) > 0) t0 = std::min(t0, tl[w * 4]);
                 for (unsigned long long x = 1; x <= 16; ++x) {
                     std::vector<unsigned long long> st, en;
-                    unsigned long long steps = 0;
+                    unsigned long long steps = 0, burst = 0;
                     for (size_t w = 0; w < 65536; ++w)
-                        if (tl[w * 4 + 2] == x && tl[w * 4 + 3] > 0) {
+                        if (tl[w * 4 + 2] == x && (tl[w * 4 + 3] & 0xFFFFF) > 0) {
                             st.push_back(tl[w * 4] - t0);
                             en.push_back(tl[w * 4 + 1] - t0);
-                            steps += tl[w * 4 + 3];
+                            steps += tl[w * 4 + 3] & 0xFFFFF;
+                            burst += tl[w * 4 + 3] >> 20;
                         }
                     if (st.empty()) continue;
                     std::sort(st.begin(), st.end());
                     std::sort(en.begin(), en.end());
                     auto q = [](const std::vector<unsigned long long> &v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
-                    fprintf(stderr, "timeline XCC%llu: %zu waves x %.1f steps | start max %llu | end min %llu p10 %llu p50 %llu p90 %llu max %llu (x10 ns)\n",
-                            x - 1, st.size(), (double)steps / st.size(), st.back(), en.front(), q(en, .1), q(en, .5), q(en, .9), en.back());
+                    fprintf(stderr, "timeline XCC%llu: %zu waves x %.1f steps (burst %.0f cycles each) | start max %llu | end min %llu p10 %llu p50 %llu p90 %llu max %llu (x10 ns)\n",
+                            x - 1, st.size(), (double)steps / st.size(), (double)burst / std::max<unsigned long long>(1, steps), st.back(), en.front(), q(en, .1), q(en, .5), q(en, .9), en.back());
                 }
             }
             fprintf(stderr, "stamps: waves*launches %llu steps %llu tasks %llu | per step: wait %.0f window %.0f rest %.0f cycles | "

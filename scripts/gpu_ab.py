@@ -2,6 +2,13 @@
 each library in its own child process.  usage: gpu_ab.py lib_base lib lib:MFX_ONE_TASK=1 lib_defer:MFX_HOT_LEN=64,MFX_GRADES=2 ..."""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES_DENSE = [  # same shape as configs[1], three widths
+    ("C2 k=32", 100000, 50000, 10000000, 32, 12),
+    ("C2 shape k=64", 100000, 50000, 10000000, 64, 8),
+    ("C2 shape k=128", 100000, 50000, 10000000, 128, 8),
+    ("C2 shape k=16", 100000, 50000, 10000000, 16, 12),
+    ("2x rows k=32", 200000, 100000, 10000000, 32, 12),
+]
 CASES = [  # name, m, n, nnz, k, epochs
     ("C2 100k x 50k 10M k=32", 100000, 50000, 10000000, 32, 12),
     ("C3-like 1M x 300k 100M k=64", 1000000, 300000, 100000000, 64, 6),
@@ -28,6 +35,9 @@ for name, m, n, nnz, k, ep in %(cases)r:
 print("AB " + json.dumps(out), flush=True)
 '''
 libs = sys.argv[1:] or ["lib"]
+if libs[0] == "--dense":
+    CASES = CASES_DENSE
+    libs = libs[1:]
 res = {}
 for lib in libs:
     env = dict(os.environ)

@@ -46,6 +46,21 @@ def test_single_pass_matches_oracle_update(pkg, orc, k, slow):
     t.close()
 
 
+def test_duplicate_ratings_apply_in_order(pkg, orc):
+    """The same (u, v) pair rated three times in a row: the second update must start from the first one's
+    result (the kernel issues a step's loads before the stores of the step before -- except here)."""
+    m = n = 2000; k = 32
+    rng = np.random.default_rng(7)
+    u = np.repeat(np.arange(m), 3); v = np.repeat(rng.permutation(n), 3)
+    R = pkg.as_nodes(u, v, rng.uniform(1, 5, 3 * m).astype(np.float32))
+    t = pkg.Trainer(R, m, n, k=k); t.init_model()
+    P, Q, PG, QG = t.get_model(); t.epoch(); t.sync(); P1, Q1, PG1, QG1 = t.get_model(); i = t.info
+    orc.sgd_apply(P, Q, PG, QG, internal(R, t), i.k_aligned, i.lambda_p_scaled, i.lambda_q_scaled, 0.1, False)
+    for got, want in ((P1, P), (Q1, Q), (PG1, PG), (QG1, QG)):
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+    t.close()
+
+
 def test_rk_fast_switch(pkg, orc):
     """rk_mode=1 uses 1/(k_a-8) for slot 1 (the AVX/scalar builds, mf.cpp:1314-1315); default is the SSE build's 1/8."""
     m = n = 1000; k = 32
