@@ -161,12 +161,20 @@ static int wgs_per_xcd_for(const mfx_options &opt, int m, int n, int ns, int cu_
     const long long stripe_rows = (n_gat + ns - 1) / ns;
     const int div = std::max(1, env_int("MFX_CONFLICT_DIV", 8));
     long long waves = stripe_rows / ((long long)div * G);
+    // Small stripes: the head of the popularity distribution weighs more the fewer rows share a
+    // stripe, and the RMSE gap to the sequential reference grows (+2.0..2.9 % at 2500 rows per stripe,
+    // +0.5 % with a third of the waves; profiles/experiments/r01_small_stripe_concurrency.log).  Below
+    // 7500 rows the cap therefore falls with the square of the stripe size.  Speed is not at stake there.
+    if (stripe_rows < 7500) waves = waves * stripe_rows / 7500;
     if (waves < 4) { // tiny problem: one workgroup per XCD with 1..3 live waves
         *waves_per_wg = (int)std::max<long long>(1, waves);
         return 1;
     }
     long long wgs = (waves + 3) / 4;
-    const long long cap = (long long)cu_per_xcd * std::max(1, env_int("MFX_MAX_WG_PER_CU", 8));
+    // Occupancy cap: about 64 ratings in flight per CU (2 workgroups of 4 waves at 8 ratings per wave).
+    // The step is bound by instruction issue once a SIMD holds two waves; more waves only shorten the
+    // tasks and crowd the L2 (sweep: profiles/experiments/r01_occupancy_sweep.log).
+    const long long cap = (long long)cu_per_xcd * std::max(1, env_int("MFX_MAX_WG_PER_CU", std::max(1, 16 / G)));
     if (wgs > cap) wgs = cap;
     if (wgs < 1) wgs = 1;
     return (int)wgs;
