@@ -126,6 +126,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # One explicit stream for everything: the trainers' launches (handle passed to mfx_trainer_epoch) and the
+    # RCCL calls torch makes on the current stream.  The default stream's handle is 0, which the C-ABI reads
+    # as "use the trainer's own stream" -- the stripe exchange would then not be ordered behind the kernels.
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":

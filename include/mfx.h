@@ -86,6 +86,13 @@ int mfx_trainer_create(const mfx_node *R_host, long long nnz, int m, int n,
 /* Same, ratings already resident in HBM (device pointer). */
 int mfx_trainer_create_device(const void *R_dev, long long nnz, int m, int n,
                               const mfx_options *opt, mfx_trainer **out);
+/* Same, with the id layout taken from the caller's row counts (per ORIGINAL id, m and n ints; NULL = the
+ * data's own) instead of this trainer's ratings: trainers that share factor rows -- the stripe trainers of
+ * one rank share P, the ranks of a job exchange Q stripes (multi.py) -- must place every id in the same
+ * row, and they do when they are given the same counts.  Exactly one of R_host / R_dev is non-NULL. */
+int mfx_trainer_create_layout(const mfx_node *R_host, const void *R_dev, long long nnz, int m, int n,
+                              const mfx_options *opt, const int *layout_cnt_p, const int *layout_cnt_q,
+                              mfx_trainer **out);
 void mfx_trainer_destroy(mfx_trainer *t);
 
 /* Use caller-owned device buffers for the factors (k_aligned stride, internal ids):

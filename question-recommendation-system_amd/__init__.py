@@ -82,6 +82,7 @@ def lib():
     vp, ll, i32 = C.c_void_p, C.c_longlong, C.c_int
     L.mfx_trainer_create.argtypes = [vp, ll, i32, i32, C.POINTER(Options), C.POINTER(vp)]
     L.mfx_trainer_create_device.argtypes = [vp, ll, i32, i32, C.POINTER(Options), C.POINTER(vp)]
+    L.mfx_trainer_create_layout.argtypes = [vp, vp, ll, i32, i32, C.POINTER(Options), vp, vp, C.POINTER(vp)]
     L.mfx_trainer_destroy.argtypes = [vp]
     L.mfx_trainer_destroy.restype = None
     L.mfx_trainer_bind_model.argtypes = [vp, vp, vp, vp, vp]
@@ -220,10 +221,21 @@ def rmse_array(model, R):
 class Trainer:
     """Handle on one training problem resident in HBM (mfx_trainer_*)."""
 
-    def __init__(self, R, m, n, opts=None, device_ptr=None, nnz=None, **kw):
+    def __init__(self, R, m, n, opts=None, device_ptr=None, nnz=None, layout_counts=None, **kw):
+        """layout_counts=(cnt_p, cnt_q): row counts per original id (either may be None) that fix the id
+        layout instead of this trainer's own ratings (mfx_trainer_create_layout)."""
         self.opts = opts if opts is not None else default_options(**kw)
         self._h = C.c_void_p()
-        if device_ptr is not None:
+        if layout_counts is not None:
+            cp, cq = (None if c is None else np.ascontiguousarray(c, dtype=np.int32) for c in layout_counts)
+            assert (cp is None or len(cp) == m) and (cq is None or len(cq) == n)
+            if device_ptr is None:
+                R = np.ascontiguousarray(R, dtype=NODE)
+                nnz = len(R)
+            _check(lib().mfx_trainer_create_layout(None if device_ptr is not None else R.ctypes.data, device_ptr, nnz,
+                                                   m, n, C.byref(self.opts), None if cp is None else cp.ctypes.data,
+                                                   None if cq is None else cq.ctypes.data, C.byref(self._h)))
+        elif device_ptr is not None:
             _check(lib().mfx_trainer_create_device(device_ptr, nnz, m, n, C.byref(self.opts), C.byref(self._h)))
         else:
             R = np.ascontiguousarray(R, dtype=NODE)

@@ -165,6 +165,28 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
             __syncthreads();
             if (!wave_on) continue;
             int c = __builtin_amdgcn_readfirstlane(wg_first) + (int)(threadIdx.x >> 6);
+            // ---- L2 warm-up ----
+            // The L2 is invalidated between launches, so the first touch of every row is a miss to
+            // MALL/HBM, and the first steps of a wave are chains of such misses (measured: the
+            // first 16 steps of a task cost 3.3x the later ones, 20 % of a launch).  When the two
+            // stripes of the block fit the L2, every wave first streams its share of them with
+            // independent, wide loads: one memory latency instead of a dozen in a row.
+            if (a.warm && c < a.waves_per_xcd) {
+                f4 sink = zero4;
+                auto stream_in = [&](const float *base, size_t floats) {
+                    for (size_t off = (size_t)c * 256 + (size_t)lane * 4; off < floats; off += (size_t)a.waves_per_xcd * 256) {
+                        const f4 v = *(const f4 *)(base + off);
+                        sink.x += v.x; sink.y += v.y; sink.z += v.z; sink.w += v.w;
+                    }
+                };
+                const size_t of = (size_t)a.own_first[slot], on_ = (size_t)a.own_n[slot];
+                const size_t gf = (size_t)a.gat_first[slot], gn_ = (size_t)a.gat_n[slot];
+                stream_in(a.gat_rows + gf * ka, gn_ * ka & ~(size_t)3);
+                stream_in(a.own_rows + of * ka, on_ * ka & ~(size_t)3);
+                stream_in(a.gat_acc + gf * 2, gn_ * 2 & ~(size_t)3);
+                stream_in(a.own_acc + of * 2, on_ * 2 & ~(size_t)3);
+                asm volatile("" ::"v"(sink.x), "v"(sink.y), "v"(sink.z), "v"(sink.w)); // keep the loads
+            }
             if (c >= ntask) continue;
             // the descriptor is the same for every lane: keep it in SGPRs, so that the step loop
             // below branches on scalars (real branches, no exec-masked loop exits)
@@ -179,6 +201,9 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
             }
             for (;;) {
                 int cn_v = 0, cn = ntask; // the next task: claim in flight / claimed index
+                // the waves of an XCD start their tasks together: spread their claims over 16 steps
+                // (atomics on one address take ~70 cycles each, 14k cycles for 196 waves at once)
+                const int claim_at = nsteps > 18 ? (c & 15) : 0;
                 TaskDescD tdn_v = {0, 0, 0};
                 unsigned long long toff_n = 0;
                 int nsteps_n = 0;
@@ -276,10 +301,10 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     // re-waits with vmcnt(0) at later uses of these registers, i.e. behind the
                     // stores below, which costs a full store round trip per step.
                     asm volatile("" : "+v"(g.x), "+v"(g.y), "+v"(g.z), "+v"(g.w), "+v"(gg.x), "+v"(gg.y));
-                    if (step < 3) { // the next task, one dependent access per step (scalar branches)
-                        if (step == 0) {
+                    if ((unsigned)(step - claim_at) < 3u) { // the next task, one dependent access per step (scalar branches)
+                        if (step == claim_at) {
                             cn_v = claim();
-                        } else if (step == 1) {
+                        } else if (step == claim_at + 1) {
                             cn = __builtin_amdgcn_readfirstlane(cn_v);
                             if (cn < ntask) tdn_v = a.tasks[tbeg + cn];
                         } else if (cn < ntask) {
@@ -385,8 +410,8 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     STAMP(ts3);
 #ifdef MFX_STAMPS
                     c_wait += ts1 - ts0;
+                    if (step < 16) c_burst += ts3 - ts0; // (diagnostic) cycles of the first 16 steps of a task
                     c_win += ts2 - ts1;
-                    c_burst += ts2 - tsb;
                     c_rest += ts3 - ts2;
                     n_steps++;
 #endif
@@ -396,13 +421,14 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     if (lig == 0) *(f2 *)(a.own_acc + (size_t)cur * 2) = f2{og0, og1};
                 }
                 if (lig == 0) lsum += (double)tsum;
-                // a task of fewer than three steps has not finished the hand-over: do the rest now
+                // a task that ended before the hand-over was through does the rest now
                 STAMP(tk0);
-                if (nsteps < 2) {
+                if (nsteps < claim_at + 1) cn_v = claim();
+                if (nsteps < claim_at + 2) {
                     cn = __builtin_amdgcn_readfirstlane(cn_v);
                     if (cn < ntask) tdn_v = a.tasks[tbeg + cn];
                 }
-                if (nsteps < 3 && cn < ntask) {
+                if (nsteps < claim_at + 3 && cn < ntask) {
                     toff_n = uniform_off(tdn_v);
                     nsteps_n = __builtin_amdgcn_readfirstlane((int)tdn_v.nsteps);
                     fetch_first(toff_n, nsteps_n, nb0, nb1);

@@ -384,8 +384,9 @@ void plan_maps(const PlanConfig &cfg, Plan &p, const int *cnt_p, const int *cnt_
         equal_ranges(p.m, p.ns, p.p_begin);
         equal_ranges(p.n, p.ns, p.q_begin);
     } else {
-        std::thread tq([&] { balanced_map(p.n, p.ns, cnt_q, p.q_map, p.q_begin, p.q_at); });
-        balanced_map(p.m, p.ns, cnt_p, p.p_map, p.p_begin, p.p_at);
+        const int *lp = cfg.layout_cnt_p ? cfg.layout_cnt_p : cnt_p, *lq = cfg.layout_cnt_q ? cfg.layout_cnt_q : cnt_q;
+        std::thread tq([&] { balanced_map(p.n, p.ns, lq, p.q_map, p.q_begin, p.q_at); });
+        balanced_map(p.m, p.ns, lp, p.p_map, p.p_begin, p.p_at);
         tq.join();
     }
     p.omega_p.assign(p.m, 0); // omega, mf.cpp:815-816

@@ -47,6 +47,9 @@ struct PlanConfig {
     int task_steps = 0;       // 0 = auto
     int owner_side = 0;       // 0 auto, 1 users, 2 items
     int map_mode = 0;         // 0 mass-balanced stripes, 1 identity, 2 the reference's shuffle (equal-count stripes)
+    // map_mode 0: balance with these counts (per ORIGINAL id) instead of the data's own, so that several
+    // trainers -- the stripe trainers of one rank, the ranks of a job -- agree on the row of every id
+    const int *layout_cnt_p = nullptr, *layout_cnt_q = nullptr;
     bool use_stats = false;   // take avg/std from below instead of collect_info
     float stats_avg = 0, stats_std = 0;
     int waves_per_stripe = 256; // for auto task sizing

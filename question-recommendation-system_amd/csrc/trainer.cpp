@@ -210,7 +210,8 @@ static int check_options(const mfx_options &opt)
 }
 
 static int create_impl(const mfx::Node *R, const void *R_dev, long long nnz, int m, int n,
-                       const mfx_options *opt_in, mfx_trainer **out)
+                       const mfx_options *opt_in, mfx_trainer **out, const int *layout_cnt_p = nullptr,
+                       const int *layout_cnt_q = nullptr)
 {
     if (!out) return fail(MFX_E_ARG, "null output handle");
     *out = nullptr;
@@ -257,6 +258,8 @@ static int create_impl(const mfx::Node *R, const void *R_dev, long long nnz, int
     t->wg_per_cu = (t->wgs_per_xcd + cu_per_xcd - 1) / cu_per_xcd;
 
     mfx::PlanConfig cfg = plan_config(opt, stripes, t->wgs_per_xcd, t->waves_per_wg);
+    cfg.layout_cnt_p = layout_cnt_p;
+    cfg.layout_cnt_q = layout_cnt_q;
 
     // Pre-processing: on the device (prep.hip) unless forced to the host builder (MFX_HOST_PLAN=1)
     // or the ids do not fit the sort key.  R may be host memory (uploaded once) or already in HBM.
@@ -361,6 +364,20 @@ int mfx_trainer_create(const mfx_node *R_host, long long nnz, int m, int n, cons
 {
     try {
         return create_impl((const mfx::Node *)R_host, nullptr, nnz, m, n, opt, out);
+    } catch (const std::exception &e) {
+        return fail(MFX_E_STATE, e.what());
+    } catch (...) {
+        return fail(MFX_E_STATE, "unknown failure");
+    }
+}
+
+int mfx_trainer_create_layout(const mfx_node *R_host, const void *R_dev, long long nnz, int m, int n,
+                              const mfx_options *opt, const int *layout_cnt_p, const int *layout_cnt_q,
+                              mfx_trainer **out)
+{
+    try {
+        return create_impl((const mfx::Node *)R_host, R_host ? nullptr : R_dev, nnz, m, n, opt, out, layout_cnt_p,
+                           layout_cnt_q);
     } catch (const std::exception &e) {
         return fail(MFX_E_STATE, e.what());
     } catch (...) {
@@ -543,8 +560,8 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
                     std::sort(st.begin(), st.end());
                     std::sort(en.begin(), en.end());
                     auto q = [](const std::vector<unsigned long long> &v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
-                    fprintf(stderr, "timeline XCC%llu: %zu waves x %.1f steps (burst %.0f cycles each) | start max %llu | end min %llu p10 %llu p50 %llu p90 %llu max %llu (x10 ns)\n",
-                            x - 1, st.size(), (double)steps / st.size(), (double)burst / std::max<unsigned long long>(1, steps), st.back(), en.front(), q(en, .1), q(en, .5), q(en, .9), en.back());
+                    fprintf(stderr, "timeline XCC%llu: %zu waves x %.1f steps (first 16 steps of the tasks: %.0f cycles) | start max %llu | end min %llu p10 %llu p50 %llu p90 %llu max %llu (x10 ns)\n",
+                            x - 1, st.size(), (double)steps / st.size(), (double)burst / std::max<size_t>(1, st.size()), st.back(), en.front(), q(en, .1), q(en, .5), q(en, .9), en.back());
                 }
             }
             fprintf(stderr, "stamps: waves*launches %llu steps %llu tasks %llu | per step: wait %.0f window %.0f rest %.0f cycles | "
@@ -567,8 +584,26 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
         if (!e0 || !e1) return fail(MFX_E_HIP, "hipEventCreate failed");
         HIP_TRY(hipEventRecord(e0, s));
     }
+    // L2 warm-up: only when every block's two stripes (rows + accumulators) fit the XCD's L2 with room to spare
+    const std::vector<int> &own_begin = p.owner_is_q ? p.q_begin : p.p_begin, &gat_begin = p.owner_is_q ? p.p_begin : p.q_begin;
+    int max_own = 0, max_gat = 0;
+    for (int x = 0; x < ns; ++x) {
+        max_own = std::max(max_own, own_begin[x + 1] - own_begin[x]);
+        max_gat = std::max(max_gat, gat_begin[x + 1] - gat_begin[x]);
+    }
+    const size_t warm_bytes = ((size_t)max_own + max_gat) * ((size_t)p.ka * 4 + 8);
+    a.warm = ns <= mfx::WARM_SLOTS && warm_bytes <= (size_t)env_int("MFX_WARM_KB", 3072) * 1024 ? 1 : 0;
+    a.waves_per_xcd = t->wgs_per_xcd * t->waves_per_wg;
     for (int i = i_begin; i < i_end; ++i) {
         const int r = (int)((i + t->epochs_done) % ns); // rotate the starting round per epoch
+        if (a.warm)
+            for (int x = 0; x < ns; ++x) { // slot x of round r: owner stripe x, gathered stripe (x + r) mod ns
+                const int g = (x + r) % ns;
+                a.own_first[x] = own_begin[x];
+                a.own_n[x] = own_begin[x + 1] - own_begin[x];
+                a.gat_first[x] = gat_begin[g];
+                a.gat_n[x] = gat_begin[g + 1] - gat_begin[g];
+            }
         a.slot_task_ptr = t->dSlotPtr.p + (size_t)r * ns;
         a.slot_cursor = t->dSlotState.p + (size_t)r * ns;
         HIP_TRY(mfx::launch_sgd_round(p.lanes, a, grid, s));

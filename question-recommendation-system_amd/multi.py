@@ -106,11 +106,12 @@ class RotatingTrainer:
             Rs["v"] -= s * self.seg
             if len(Rs) == 0:
                 raise ValueError("rank %d holds no rating for item stripe %d" % (rank, s))
-            # identity_maps=2: the reference's data-independent id layout -- the N trainers of a rank share
-            # one P, so they must all place a user in the same row
-            opts = pkg.default_options(use_stats=1, stats_avg=float(avg), stats_std=float(std),
-                                       **{"identity_maps": 2, **opt_kw})
-            self.trainers.append(pkg.Trainer(Rs, m, self.seg, opts=opts))
+            # The N stripe trainers of a rank share one P, and a Q stripe visits every rank: all of them must
+            # put an id in the same row.  The mass-balanced layout is therefore built from shared counts:
+            # this rank's user counts and the GLOBAL item counts of the stripe (mfx_trainer_create_layout).
+            opts = pkg.default_options(use_stats=1, stats_avg=float(avg), stats_std=float(std), **opt_kw)
+            self.trainers.append(pkg.Trainer(Rs, m, self.seg, opts=opts,
+                                             layout_counts=(cnt_p, cnt_q[s * self.seg:(s + 1) * self.seg])))
         i0 = self.trainers[0].info
         self.ka = i0.k_aligned
         self.nnz = sum(t.info.nnz for t in self.trainers)
@@ -153,7 +154,12 @@ class RotatingTrainer:
                 rcv.copy_(h_r)
 
     def epoch(self, slow_only=False, stream=None):
+        """stream: handle of the (non-default) stream that is torch's current stream, so that the launches and
+        the RCCL calls of the ring shift are ordered on it.  Handle 0 / None would send every stripe trainer to
+        a stream of its own."""
         N = self.world
+        if N > 1 and not stream:
+            raise ValueError("RotatingTrainer.epoch needs the handle of a non-default stream (torch.cuda.Stream)")
         for s in range(N):
             cur = (self.rank + s) % N
             self.trainers[cur].epoch(slow_only=slow_only, stream=stream)

@@ -10,14 +10,17 @@ spec = importlib.util.spec_from_file_location("qrs_multi", os.path.join(ge.PKG_D
 m,n,nnz,k = 100000,50000,10000000,32
 R = pkg.synth_host(1,0,nnz,m,n)
 dev = torch.device("cuda",0)
-for N in (1,2,4,8):
+for N in ([int(x) for x in sys.argv[1:]] or [1,2,4,8]):
     t = multi.RotatingTrainer(pkg, R, m, n, N, 0, None, dev, k=k)
-    st = torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream(device=dev)  # a real stream: handle 0 would mean "each trainer's own stream"
+    st = side.cuda_stream
     t.epoch(slow_only=True, stream=st)
     for _ in range(3): t.epoch(stream=st)
     torch.cuda.synchronize(); t0=time.time()
     for _ in range(10): t.epoch(stream=st)
+    t_enq=(time.time()-t0)/10   # host time to enqueue an epoch
     torch.cuda.synchronize(); dt0=(time.time()-t0)/10
+    print("   host enqueue %.3f ms/epoch" % (t_enq*1e3))
     t.timing_enable(True); t0=time.time()
     for _ in range(10): t.epoch(stream=st)
     torch.cuda.synchronize(); dt=(time.time()-t0)/10; nl,ms=t.timing_read()

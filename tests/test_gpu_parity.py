@@ -222,9 +222,10 @@ def test_stripe_rotation_one_rank_is_plain_sgd(pkg, orc, world):
     t = multi.RotatingTrainer(pkg, R, m, n, world, 0, None, torch.device("cuda", 0), k=k)
     assert sum(x.info.nnz for x in t.trainers) == nnz
     assert len({(x.info.scale, x.info.avg) for x in t.trainers}) == 1  # ONE common scale (use_stats)
-    st = torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()  # one explicit stream for all stripe trainers (handle 0 = each trainer's own)
     for it in range(iters):
-        t.epoch(slow_only=(it == 0), stream=st)
+        t.epoch(slow_only=(it == 0), stream=side.cuda_stream)
+    side.synchronize()
     got = t.rmse()
     t.close()
     os.environ.pop("MFX_HOT_LEN")
