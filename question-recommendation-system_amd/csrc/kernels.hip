@@ -22,6 +22,13 @@
 //    serves the blocks of its own XCD (rank, rank+X, ...): which workgroup lands where
 //    changes speed, never results.  Inside a block the XCD's waves run lock-free (Hogwild)
 //    on the gathered side; factor loads bypass the per-CU L1 so they see the XCD's L2.
+//  * The number of ratings in flight is capped (lost updates cost RMSE), so the time of a
+//    launch is (steps per wave) x (latency of one step), and a step is a chain: L2 round
+//    trip + the wave's own instructions.  vmcnt retires in order on gfx9 and hipcc waits
+//    conservatively across branches, so the loop is laid out around its waits: one burst of
+//    memory operations per step with one settle point, entries streamed through a per-wave
+//    LDS ring in blocks, the next task claimed/fetched while the current one runs, the
+//    block's stripes streamed into L2 before the first step.  Comments at each piece.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -254,6 +254,38 @@ def test_config2_full_size(pkg):
     assert abs(rm - 0.94767) / 0.94767 < 0.03, rm        # observed 0.925-0.928: the GPU path is slightly ahead
 
 
+def test_shared_layout_from_common_counts(pkg, orc):
+    """mfx_trainer_create_layout: trainers over different parts of one problem that are given the same row
+    counts place every id in the same row (what lets the stripe trainers of a rank share P and a Q stripe
+    visit every rank), on the host-rating and the device-rating path alike; the layout is still balanced
+    and the initial factors are the reference's per original id."""
+    import torch
+    m, n, nnz, k = 6000, 4000, 600000, 32
+    R = pkg.synth_host(4, 0, nnz, m, n)
+    cp = np.bincount(R["u"], minlength=m).astype(np.int32)
+    cq = np.bincount(R["v"], minlength=n).astype(np.int32)
+    halves = [R[: nnz // 2], R[nnz // 2:]]
+    ts = [pkg.Trainer(h, m, n, k=k, layout_counts=(cp, cq)) for h in halves]
+    d = torch.from_numpy(halves[1].copy().view(np.int32).reshape(-1)).cuda()
+    ts.append(pkg.Trainer(None, m, n, opts=pkg.default_options(k=k), device_ptr=d.data_ptr(), nnz=len(halves[1]),
+                          layout_counts=(cp, cq)))
+    ref = pkg.HostPlan(R, m, n, k=k)  # the whole problem: its own counts are the shared ones
+    for t in ts:
+        pm, qm = t.maps()
+        assert np.array_equal(pm, ref.p_map) and np.array_equal(qm, ref.q_map)
+    own = pkg.Trainer(halves[0], m, n, k=k)  # without shared counts the layout follows the part's own data
+    assert not np.array_equal(own.maps()[0], ref.p_map)
+    # same counts for init -> same initial factors in all of them
+    for t in ts:
+        t.init_model_counts(cp, cq)
+    P0, Q0 = ref.init_factors()
+    for t in ts:
+        P, Q, _, _ = t.get_model()
+        assert np.array_equal(P.view(np.uint32), P0.view(np.uint32)) and np.array_equal(Q.view(np.uint32), Q0.view(np.uint32))
+    for t in ts + [own]:
+        t.close()
+
+
 @pytest.mark.parametrize("shape", [(3000, 2000, 90000, 32), (500, 4000, 60000, 8), (20000, 9000, 1500000, 64)])
 def test_device_preprocessing_equals_host_builder(pkg, orc, shape):
     """prep.hip (statistics, relabel, scale, radix sort, visit table on the GPU) must produce the very layout
