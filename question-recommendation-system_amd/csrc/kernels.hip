@@ -208,9 +208,12 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
             }
             for (;;) {
                 int cn_v = 0, cn = ntask; // the next task: claim in flight / claimed index
-                // the waves of an XCD start their tasks together: spread their claims over 16 steps
-                // (atomics on one address take ~70 cycles each, 14k cycles for 196 waves at once)
-                const int claim_at = nsteps > 18 ? (c & 15) : 0;
+                // The claim goes out eight steps before the task ends: late enough that the waves of an
+                // XCD, which start their tasks together, do not all ask at once (atomics on one address
+                // take ~70 cycles each, 14k cycles for 196 waves, and the wait behind the claim would
+                // cover them), early enough for descriptor and entries to arrive under the last steps;
+                // and the waves that run ahead are the ones that get what is left.
+                const int claim_at = nsteps > 12 ? nsteps - 8 : 0;
                 TaskDescD tdn_v = {0, 0, 0};
                 unsigned long long toff_n = 0;
                 int nsteps_n = 0;

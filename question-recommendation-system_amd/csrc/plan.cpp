@@ -172,7 +172,7 @@ void pack_visits(std::vector<Visit> &raw, int G, int target, int hot_len, BlockP
     // Graded task sizes: the first half of the work goes into full-size tasks, then a
     // quarter at half size, ... so the waves that drain the block's queue last are holding
     // short tasks (the launch ends when the slowest wave does).
-    if (one_task_waves > 0) { // experiment: exactly one task per wave of the block's XCD
+    if (one_task_waves > 0) { // equal-load tasks, (tasks per wave) x (waves of the block's XCD) of them
         pack_class(visits, 0, visits.size(), G, 8, out, one_task_waves);
         return;
     }
