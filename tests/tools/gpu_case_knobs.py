@@ -1,7 +1,7 @@
 """One parity case under several environment settings (each in a child process): RMSE vs the oracle.
 usage: gpu_case_knobs.py m n nnz k iters seed  ENV=VAL[,ENV=VAL] ..."""
 import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 m, n, nnz, k, iters, seed = (int(x) for x in sys.argv[1:7])
 CHILD = r'''
 import os, sys

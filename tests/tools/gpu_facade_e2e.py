@@ -2,7 +2,7 @@
 (BASELINE configs[1] size, 20 iterations), beside the reference's own utility_train pipeline (mf_train, 12 threads)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as ge
 pkg = ge.import_package(); orc = ge.import_oracle()
 m,n,nnz,k,iters = 100000,50000,10000000,32,20

@@ -2,7 +2,7 @@
 (same triples, epochs, hyper-parameters).  Prints a markdown table."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as ge
 pkg = ge.import_package(); orc = ge.import_oracle()
 cases = [(3000,2000,100000,8,10),(2000,1500,120000,16,8),(20000,10000,2000000,32,10),(20000,10000,2000000,64,8),

@@ -1,7 +1,7 @@
 """Why does a 2-stripe rotation of a small problem lose RMSE vs the single trainer?  Knob study."""
 import os, sys, importlib.util
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as ge
 import torch
 pkg = ge.import_package(); orc = ge.import_oracle()

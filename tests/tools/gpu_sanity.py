@@ -1,7 +1,7 @@
 """First-contact GPU script: correctness of the hot path vs the oracle + a quick speed sweep."""
 import os, sys, time, json
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as ge
 pkg = ge.import_package(); orc = ge.import_oracle()
 out = {}

@@ -2,7 +2,7 @@
 usage: gpu_single_pass.py lib [lib_x ...]"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as ge
 pkg = ge.import_package(); orc = ge.import_oracle()
 libs = sys.argv[1:] or ["lib"]
