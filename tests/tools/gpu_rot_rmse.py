@@ -1,4 +1,4 @@
-"""Why does a 2-stripe rotation of a small problem lose RMSE vs the single trainer?  Knob study."""
+"""One rank of the N-stripe rotation without peers: RMSE and epoch time vs the hot-chain length."""
 import os, sys, importlib.util
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -15,11 +15,17 @@ want = orc.rmse(R, orc.train(R, m, n, k=k, iters=iters)); print("oracle", want, 
 def rot(world, **env):
     for a,b in env.items(): os.environ[a]=str(b)
     t = multi.RotatingTrainer(pkg, R, m, n, world, 0, None, torch.device("cuda", 0), k=k)
-    st = torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream(); st = side.cuda_stream  # one explicit stream for all stripe trainers
     for it in range(iters): t.epoch(slow_only=(it == 0), stream=st)
+    side.synchronize()
+    import time
+    t0 = time.time()
+    for it in range(5): t.epoch(stream=st)
+    side.synchronize(); dt = (time.time() - t0) / 5
     r = t.rmse(); i=t.trainers[0].info
-    print("world=%d %s: rmse %.4f (%+.1f%%) wg/cu~%d tasks %d hot %d" % (world, env, r, (r-want)/want*100, i.wg_per_cu, i.n_tasks, i.n_hot_rows), flush=True)
+    print("world=%d %s: rmse@%d %.4f (%+.1f%% vs oracle@%d) %.3f ms/epoch  wg/cu~%d tasks %d hot %d" % (world, env, iters + 5, r, (r-want)/want*100, iters, dt*1e3, i.wg_per_cu, i.n_tasks, i.n_hot_rows), flush=True)
     t.close()
     for a in env: os.environ.pop(a)
-for rep in range(2):
-    rot(1); rot(1, MFX_WIDE=0)
+for world in (1, 4, 8):
+    for hl in (None, 16, 32, 64, 128):
+        rot(world, **({} if hl is None else {"MFX_HOT_LEN": hl}))
