@@ -79,6 +79,34 @@ __device__ __forceinline__ f4 ld_row(const float *p) { return *(const f4 *)p; }
 __device__ __forceinline__ f2 ld_acc(const float *p) { return *(const f2 *)p; }
 #endif
 
+// Gathered-side accesses through a raw buffer descriptor over the block's gathered stripe: 32-bit offsets
+// (one or two VALU instructions instead of a 64-bit address chain), and the hardware range check does
+// the pad entries and the lanes past k_a -- an offset beyond the stripe loads zeros and drops the store.
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+constexpr unsigned BUF_OOB = 0xFFFFFF00u; // beyond any stripe
+constexpr int BUF_NT = 2;                  // aux: non-temporal, like ld_row (past the per-CU L1)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f4 bld_row(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, BUF_NT));
+}
+__device__ __forceinline__ f2 bld_acc(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    return __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, BUF_NT));
+}
+__device__ __forceinline__ void bst_row(__amdgpu_buffer_rsrc_t r, unsigned off, f4 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), r, (int)off, 0, 0);
+}
+__device__ __forceinline__ void bst_acc(__amdgpu_buffer_rsrc_t r, unsigned off, f2 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), r, (int)off, 0, 0);
+}
+
 #ifdef MFX_STAMPS
 // Diagnostic build only (`make diag` -> lib_diag/): s_memtime stamps around the segments of a step.
 // The sums go to a buffer of their own; no result depends on them; the shipped library has none of this.
@@ -145,6 +173,12 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
         for (int slot = rank; slot < a.ns; slot += a.n_xcc) {
             const long long tbeg = a.slot_task_ptr[slot];
             const int ntask = (int)(a.slot_task_ptr[slot + 1] - tbeg);
+            // the block's stripes: owner stripe = slot, gathered stripe = (slot + round) mod ns
+            const int gs = (slot + a.round) % a.ns;
+            const int ofirst = a.own_begin[slot], on_rows = a.own_begin[slot + 1] - ofirst;
+            const int gfirst = a.gat_begin[gs], gn_rows = a.gat_begin[gs + 1] - gfirst;
+            const __amdgpu_buffer_rsrc_t rs_rows = make_rsrc(a.gat_rows + (size_t)gfirst * ka, (unsigned)gn_rows * (unsigned)(ka * 4));
+            const __amdgpu_buffer_rsrc_t rs_acc = make_rsrc(a.gat_acc + (size_t)gfirst * 2, (unsigned)gn_rows * 8u);
             // A task costs a chain of dependent misses before its first step: claim (atomic), descriptor,
             // entries, rows.  Only the first task of a wave pays it in full: while a task runs, its
             // first three steps claim the NEXT one, read its descriptor and fetch its first block of
@@ -186,8 +220,7 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                         sink.x += v.x; sink.y += v.y; sink.z += v.z; sink.w += v.w;
                     }
                 };
-                const size_t of = (size_t)a.own_first[slot], on_ = (size_t)a.own_n[slot];
-                const size_t gf = (size_t)a.gat_first[slot], gn_ = (size_t)a.gat_n[slot];
+                const size_t of = (size_t)ofirst, on_ = (size_t)on_rows, gf = (size_t)gfirst, gn_ = (size_t)gn_rows;
                 stream_in(a.gat_rows + gf * ka, gn_ * ka & ~(size_t)3);
                 stream_in(a.own_rows + of * ka, on_ * ka & ~(size_t)3);
                 stream_in(a.gat_acc + gf * 2, gn_ * 2 & ~(size_t)3);
@@ -270,12 +303,13 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                 // round trip of the next one.  The time between a row's load and its store (the
                 // window in which a concurrent update of the same row is lost) keeps its length; it
                 // only starts earlier.
-                // Pad entries and lanes past k_a read and write the scratch row instead (a zero row
-                // that nothing ever changes), so that every row/accumulator access is unconditional.
-                float *grow = (e.gat >= 0 && lane_ok ? a.gat_rows + (size_t)e.gat * ka : a.scratch) + d0;
-                float *gacc = e.gat >= 0 ? a.gat_acc + (size_t)e.gat * 2 : a.scratch + SCRATCH_ROW;
-                f4 gn = ld_row(grow);
-                f2 ggn = ld_acc(gacc);
+                // The gathered side is addressed through buffer descriptors over the block's gathered
+                // stripe (32-bit offsets); pad entries and lanes past k_a use an offset beyond it --
+                // the range check loads zeros and drops the store -- so every access is unconditional.
+                unsigned grow = e.gat >= 0 && lane_ok ? (unsigned)(e.gat - gfirst) * (unsigned)(ka * 4) + d0 * 4 : BUF_OOB;
+                unsigned gacc = e.gat >= 0 ? (unsigned)(e.gat - gfirst) * 8u : BUF_OOB;
+                f4 gn = bld_row(rs_rows, grow);
+                f2 ggn = bld_acc(rs_acc, gacc);
                 STAMP(tk1);
 #ifdef MFX_STAMPS
                 c_task += tk1 - tk0;
@@ -306,7 +340,7 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     }
                     f4 g = gn;
                     f2 gg = ggn;
-                    float *const grow_c = grow, *const gacc_c = gacc;
+                    const unsigned grow_c = grow, gacc_c = gacc;
                     // One explicit settle point for the loads this step consumes.  Without it hipcc
                     // re-waits with vmcnt(0) at later uses of these registers, i.e. behind the
                     // stores below, which costs a full store round trip per step.
@@ -359,8 +393,8 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     }
                     // ---- one burst of memory operations ----
                     const bool nact = enext.gat >= 0 && step + 1 < nsteps;
-                    grow = (nact && lane_ok ? a.gat_rows + (size_t)enext.gat * ka : a.scratch) + d0;
-                    gacc = nact ? a.gat_acc + (size_t)enext.gat * 2 : a.scratch + SCRATCH_ROW;
+                    grow = nact && lane_ok ? (unsigned)(enext.gat - gfirst) * (unsigned)(ka * 4) + d0 * 4 : BUF_OOB;
+                    gacc = nact ? (unsigned)(enext.gat - gfirst) * 8u : BUF_OOB;
                     const unsigned id1 = enext.own & IDMASK;
                     auto owner_prefetch = [&]() {
                         if (nact && (enext.own >> 31) && id1 != cur) { // a visit starts at the next step
@@ -370,8 +404,8 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                         }
                     };
                     auto next_loads = [&]() {
-                        gn = ld_row(grow);
-                        ggn = ld_acc(gacc);
+                        gn = bld_row(rs_rows, grow);
+                        ggn = bld_acc(rs_acc, gacc);
                     };
                     auto acc_store = [&]() {
                         const float sg0 = group_sum<LANES>(slot1 ? 0.0f : sg);
@@ -380,12 +414,12 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                             const float sg1 = group_sum<LANES>(slot1 ? sg : 0.0f);
                             gg.y = gg.y + sg1 * rk1;
                         }
-                        *(f2 *)gacc_c = gg; // every lane of the group writes the same pair
+                        bst_acc(rs_acc, gacc_c, gg); // every lane of the group writes the same pair
                     };
                     STAMP(tsb);
                     // the gathered row goes back first: the time between its load and this store is the
                     // window in which another wave's update of the same row is lost
-                    *(f4 *)grow_c = g;
+                    bst_row(rs_rows, grow_c, g);
                     if constexpr (!LOADS_FIRST) {
                         // accumulator store, then the next step's loads: the wait at the top of the next
                         // step covers the whole burst

@@ -10,9 +10,6 @@ struct EntryD { uint32_t own; int32_t gat; float r; };
 struct TaskDescD { uint64_t off; uint32_t nsteps; uint32_t pad; };
 
 constexpr int LOSS_SLOTS = 256; // the epoch loss is kept as this many partial sums
-constexpr int SCRATCH_ROW = 256;    // floats of the scratch row (64 lanes x float4)
-constexpr int SCRATCH_FLOATS = SCRATCH_ROW + 2;
-constexpr int WARM_SLOTS = 16;      // L2 warm-up is offered up to this many stripes per side
 
 // Arguments of one SGD round (= one launch = NS stripe-disjoint blocks).
 struct RoundArgs {
@@ -25,8 +22,6 @@ struct RoundArgs {
     const long long *slot_task_ptr; // ns+1 task offsets of this round
     int *slot_cursor;               // ns ints, zero before the launch
     double *loss;                   // LOSS_SLOTS partial sums of e^2 (scaled units), accumulated
-    float *scratch;                 // SCRATCH_FLOATS floats: a zero row + accumulators {1,1}; where pad
-                                    // entries and lanes past k_a load and store (never changes value)
     float lambda_own, lambda_gat, eta, rk1;
     int ka, slow_only, ns;
     int n_xcc;                      // XCDs that take work
@@ -34,11 +29,13 @@ struct RoundArgs {
 #ifdef MFX_STAMPS
     unsigned long long *stamps;     // diagnostic build only: 8 cycle sums per wave (kernels.hip, STAMP)
 #endif
-    // L2 warm-up (kernels.hip): rows of the slot's two stripes, if they fit the XCD's L2
+    // stripes: internal-id boundaries (ns+1 ints each, device memory); slot s of round r works on owner
+    // stripe s and gathered stripe (s + r) mod ns.  The kernel addresses the gathered side through buffer
+    // descriptors over that stripe (a stripe must stay below 4 GB) and can stream both stripes into L2.
+    const int *own_begin, *gat_begin;
+    int round;
     int warm;                       // 1: stream the stripes of each slot into L2 before the first step
     int waves_per_xcd;              // waves that take work in one XCD (warm-up chunks are dealt over them)
-    int own_first[WARM_SLOTS], own_n[WARM_SLOTS]; // per slot: first row and row count of the owner stripe
-    int gat_first[WARM_SLOTS], gat_n[WARM_SLOTS]; //           ... of the gathered stripe
     signed char xcc_rank[16];       // HW_REG_XCC_ID -> rank in [0, n_xcc), -1 = takes no work
 };
 

@@ -98,7 +98,7 @@ struct mfx_trainer {
     DevBuf<int> dSlotState; // per round: cursor[ns]
     DevBuf<double> dScalars; // [0..3] scratch for metrics
     DevBuf<double> dLoss;    // LOSS_SLOTS partial sums of the epoch's online loss
-    DevBuf<float> dScratch;  // RoundArgs::scratch
+    DevBuf<int> dOwnBegin, dGatBegin; // RoundArgs::own_begin / gat_begin (ns+1 each)
     DevBuf<int> dOmegaP, dOmegaQ, dPmap, dQmap;
     DevBuf<float> oP, oQ, oPG, oQG; // owned factor storage
     float *dP = nullptr, *dQ = nullptr, *dPG = nullptr, *dQG = nullptr;
@@ -324,10 +324,17 @@ static int create_impl(const mfx::Node *R, const void *R_dev, long long nnz, int
         HIP_TRY(t->dLoss.alloc(mfx::LOSS_SLOTS));
         HIP_TRY(hipMemset(t->dLoss.p, 0, mfx::LOSS_SLOTS * sizeof(double)));
         {
-            float scratch[mfx::SCRATCH_FLOATS] = {0.0f};
-            scratch[mfx::SCRATCH_ROW] = scratch[mfx::SCRATCH_ROW + 1] = 1.0f;
-            HIP_TRY(t->dScratch.alloc(mfx::SCRATCH_FLOATS));
-            HIP_TRY(hipMemcpy(t->dScratch.p, scratch, sizeof(scratch), hipMemcpyHostToDevice));
+            // stripe boundaries for the kernel (buffer descriptors over the gathered stripe, L2 warm-up)
+            const std::vector<int> &ob = p.owner_is_q ? p.q_begin : p.p_begin, &gb = p.owner_is_q ? p.p_begin : p.q_begin;
+            for (int x = 0; x < p.ns; ++x)
+                if ((unsigned long long)(gb[x + 1] - gb[x]) * p.ka * 4ull >= 0xFFFFFF00ull) {
+                    rc = fail(MFX_E_UNSUPPORTED, "a gathered stripe of 4 GB or more: use more stripes (mfx_options.stripes)");
+                    return rc;
+                }
+            HIP_TRY(t->dOwnBegin.alloc(ob.size()));
+            HIP_TRY(t->dGatBegin.alloc(gb.size()));
+            HIP_TRY(hipMemcpy(t->dOwnBegin.p, ob.data(), ob.size() * sizeof(int), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(t->dGatBegin.p, gb.data(), gb.size() * sizeof(int), hipMemcpyHostToDevice));
         }
         HIP_TRY(t->dOmegaP.alloc(m));
         HIP_TRY(t->dOmegaQ.alloc(n));
@@ -516,7 +523,8 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
     a.entries = t->dEntries.p;
     a.tasks = t->dTasks.p;
     a.loss = t->dLoss.p;
-    a.scratch = t->dScratch.p;
+    a.own_begin = t->dOwnBegin.p;
+    a.gat_begin = t->dGatBegin.p;
     a.lambda_own = p.owner_is_q ? t->lambda_q : t->lambda_p;
     a.lambda_gat = p.owner_is_q ? t->lambda_p : t->lambda_q;
     a.eta = t->opt.eta;
@@ -592,18 +600,11 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
         max_gat = std::max(max_gat, gat_begin[x + 1] - gat_begin[x]);
     }
     const size_t warm_bytes = ((size_t)max_own + max_gat) * ((size_t)p.ka * 4 + 8);
-    a.warm = ns <= mfx::WARM_SLOTS && warm_bytes <= (size_t)env_int("MFX_WARM_KB", 3072) * 1024 ? 1 : 0;
+    a.warm = warm_bytes <= (size_t)env_int("MFX_WARM_KB", 3072) * 1024 ? 1 : 0;
     a.waves_per_xcd = t->wgs_per_xcd * t->waves_per_wg;
     for (int i = i_begin; i < i_end; ++i) {
         const int r = (int)((i + t->epochs_done) % ns); // rotate the starting round per epoch
-        if (a.warm)
-            for (int x = 0; x < ns; ++x) { // slot x of round r: owner stripe x, gathered stripe (x + r) mod ns
-                const int g = (x + r) % ns;
-                a.own_first[x] = own_begin[x];
-                a.own_n[x] = own_begin[x + 1] - own_begin[x];
-                a.gat_first[x] = gat_begin[g];
-                a.gat_n[x] = gat_begin[g + 1] - gat_begin[g];
-            }
+        a.round = r;
         a.slot_task_ptr = t->dSlotPtr.p + (size_t)r * ns;
         a.slot_cursor = t->dSlotState.p + (size_t)r * ns;
         HIP_TRY(mfx::launch_sgd_round(p.lanes, a, grid, s));
