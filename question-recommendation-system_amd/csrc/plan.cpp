@@ -204,10 +204,11 @@ void plan_sizes(long long nnz, int NB, int G, const PlanConfig &cfg, int &target
     // A hot owner row is cut into chains of at most hot_len ratings.  Longer chains keep more of
     // the row's updates (measured: 128 vs 64 is worth 2-3 % RMSE on small problems,
     // profiles/experiments/r01_hot_chain_length.log), but a list must not outlast what one wave
-    // does in the launch, or it sets the launch time: hot_len = per-wave load, within [32,128].
+    // does in the launch, or it sets the launch time: hot_len = per-wave load, within [48,128] (48: below it the
+    // ordinary rows of small blocks get cut too -- one rank of N=8: RMSE 0.730 at 38, 0.698 at 48).
     const char *he = getenv("MFX_HOT_LEN"); // experiment knob
     hot_len = he && *he ? std::max(8, atoi(he))
-                        : (int)std::min<long long>(128, std::max<long long>(32, per_wave));
+                        : (int)std::min<long long>(128, std::max<long long>(48, per_wave));
 }
 
 void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig &cfg, Plan &p,

@@ -180,6 +180,27 @@ static int wgs_per_xcd_for(const mfx_options &opt, int m, int n, int ns, int cu_
     return (int)wgs;
 }
 
+// Stripes per side (= launches per epoch) and the launch width that goes with them.
+// Small problems (the stripe trainers of an N-GPU rotation, say): a launch has a floor of ~25 us (hand-over,
+// cold L2), so when a wave would get fewer than 32 steps per launch, half the stripes -- half the XCDs at work,
+// a quarter of the launches per epoch, four times the block -- is faster (one rank of N=8: 1.97 -> 1.46
+// ms/epoch, N=4: 1.30 -> 1.08; profiles/experiments/r01_substripes.log).
+static int choose_stripes(const mfx_options &opt, long long nnz, int m, int n, int xcd_count, int cu_per_xcd,
+                          int *wgs_per_xcd, int *waves_per_wg)
+{
+    int stripes = opt.stripes > 0 ? opt.stripes : env_int("MFX_STRIPES", xcd_count);
+    *wgs_per_xcd = wgs_per_xcd_for(opt, m, n, stripes, cu_per_xcd, waves_per_wg);
+    if (opt.stripes <= 0 && env_int("MFX_STRIPES", 0) <= 0 && stripes >= 8) {
+        const int G = 64 / mfx::lanes_for(mfx::k_aligned(opt.k));
+        const long long waves = (long long)*wgs_per_xcd * *waves_per_wg;
+        if (nnz / ((long long)stripes * stripes * G * std::max<long long>(1, waves)) < 32) {
+            stripes /= 2;
+            *wgs_per_xcd = wgs_per_xcd_for(opt, m, n, stripes, cu_per_xcd, waves_per_wg);
+        }
+    }
+    return stripes;
+}
+
 static mfx::PlanConfig plan_config(const mfx_options &opt, int stripes, int wgs_per_xcd, int waves_per_wg)
 {
     mfx::PlanConfig cfg;
@@ -252,9 +273,8 @@ static int create_impl(const mfx::Node *R, const void *R_dev, long long nnz, int
         for (int i = 0; i < 16; ++i) t->xcc_rank[i] = (mask >> i) & 1 ? (signed char)rank++ : (signed char)-1;
         t->xcd_count = rank;
     }
-    const int stripes = opt.stripes > 0 ? opt.stripes : env_int("MFX_STRIPES", t->xcd_count);
     const int cu_per_xcd = std::max(1, t->cu_count / t->xcd_count);
-    t->wgs_per_xcd = wgs_per_xcd_for(opt, m, n, stripes, cu_per_xcd, &t->waves_per_wg);
+    const int stripes = choose_stripes(opt, nnz, m, n, t->xcd_count, cu_per_xcd, &t->wgs_per_xcd, &t->waves_per_wg);
     t->wg_per_cu = (t->wgs_per_xcd + cu_per_xcd - 1) / cu_per_xcd;
 
     mfx::PlanConfig cfg = plan_config(opt, stripes, t->wgs_per_xcd, t->waves_per_wg);
@@ -942,9 +962,8 @@ int mfx_hostplan_build(const mfx_node *R, long long nnz, int m, int n, const mfx
     mfx_hostplan *h = new (std::nothrow) mfx_hostplan();
     if (!h) return fail(MFX_E_NOMEM, "out of host memory");
     try {
-        const int stripes = opt->stripes > 0 ? opt->stripes : env_int("MFX_STRIPES", 8);
-        int wpw = 4;
-        int wgs = wgs_per_xcd_for(*opt, m, n, stripes, 32, &wpw);
+        int wpw = 4, wgs = 1;
+        const int stripes = choose_stripes(*opt, nnz, m, n, 8, 32, &wgs, &wpw); // an MI355X: 8 XCDs of 32 CUs
         mfx::build_plan((const mfx::Node *)R, nnz, m, n, plan_config(*opt, stripes, wgs, wpw), h->plan);
     } catch (const std::bad_alloc &) {
         delete h;
