@@ -7,6 +7,8 @@ CASES_DENSE = [  # same shape as configs[1], three widths
     ("C2 shape k=64", 100000, 50000, 10000000, 64, 8),
     ("C2 shape k=128", 100000, 50000, 10000000, 128, 8),
     ("C2 shape k=16", 100000, 50000, 10000000, 16, 12),
+    ("C2 shape k=8", 100000, 50000, 10000000, 8, 12),
+    ("1M x 500k 50M k=8", 1000000, 500000, 50000000, 8, 6),
     ("2x rows k=32", 200000, 100000, 10000000, 32, 12),
 ]
 CASES = [  # name, m, n, nnz, k, epochs
