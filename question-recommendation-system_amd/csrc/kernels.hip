@@ -134,9 +134,6 @@ template <int LANES, bool FULL, bool SLOW>
 __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
 {
     constexpr int G = 64 / LANES;
-    // Order of the memory burst that ends a step (measured per width, profiles/experiments/r01_burst_order.log):
-    // wide rows gain from sending the next step's loads ahead of the accumulator store, narrow ones lose.
-    constexpr bool LOADS_FIRST = LANES >= 16;
     constexpr int EBLK = 128; // entries per block of the entry stream (two per lane); EBLK/G steps
     static_assert(EBLK / G >= 4, "a block of the entry stream must span at least four steps");
     constexpr unsigned NONE = 0xFFFFFFFFu, IDMASK = 0x7FFFFFFFu;
@@ -420,29 +417,14 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     // the gathered row goes back first: the time between its load and this store is the
                     // window in which another wave's update of the same row is lost
                     bst_row(rs_rows, grow_c, g);
-                    if constexpr (!LOADS_FIRST) {
-                        // accumulator store, then the next step's loads: the wait at the top of the next
-                        // step covers the whole burst
-                        acc_store();
-                        next_loads();
-                        owner_prefetch();
-                    } else {
-                        // The next step's loads go out before the accumulator reductions, and the wait at
-                        // the top of the next step (vmcnt retires in order) leaves the accumulator store
-                        // in flight.  If the next entry of a lane group names the same gathered row (a
-                        // duplicate rating), its load must see this step's accumulators: that wave stores
-                        // first and drains.
-                        const bool again = nact && act && enext.gat == e.gat;
-                        owner_prefetch();
-                        if (__builtin_amdgcn_ballot_w64(again) == 0) {
-                            next_loads();
-                            acc_store();
-                        } else {
-                            acc_store();
-                            next_loads();
-                            __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): both orders leave the same state behind
-                        }
-                    }
+                    // accumulator store, then the next step's loads: the wait at the top of the next step
+                    // covers the whole burst.  (Sending the loads ahead of the accumulator store, with the
+                    // wait leaving that store in flight, paid for wide rows before the buffer addressing and
+                    // stopped paying with it: profiles/experiments/r01_burst_order.log.)  Stores before loads
+                    // also means a duplicate rating next in the list sees this step's result.
+                    acc_store();
+                    next_loads();
+                    owner_prefetch();
                     e = enext;
                     STAMP(ts2);
                     const float so0 = group_sum<LANES>(slot1 ? 0.0f : so);
