@@ -178,6 +178,13 @@ int mfx_hostplan_view(const mfx_hostplan *h, mfx_plan_view *view);
 int mfx_hostplan_init_factors(const mfx_hostplan *h, float *P, float *Q);
 void mfx_hostplan_destroy(mfx_hostplan *h);
 
+/* read_triplet (mf/mf.cpp:3367-3394) without the host pass: `count` float triples (u, v, r) in host memory are
+ * uploaded once and turned into an mfx_node array in HBM (ids truncated like the reference's (mf_int) cast);
+ * *m = max u + 1, *n = max v + 1.  A negative id fails with MFX_E_ARG.  Feed the array to
+ * mfx_trainer_create_device; release it with mfx_device_free. */
+int mfx_triplets_to_device(const float *triplets, long long count, int device, void **d_nodes, int *m, int *n);
+void mfx_device_free(void *p);
+
 /* Deterministic synthetic ratings: integer-only generator, identical on
  * host and device.  Writes ratings [first, first+count) of shard `shard` of problem `seed`:
  * a shard is one GPU's user range (m users of its own, the n items shared by all shards);

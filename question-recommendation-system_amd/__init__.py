@@ -83,6 +83,9 @@ def lib():
     L.mfx_trainer_create.argtypes = [vp, ll, i32, i32, C.POINTER(Options), C.POINTER(vp)]
     L.mfx_trainer_create_device.argtypes = [vp, ll, i32, i32, C.POINTER(Options), C.POINTER(vp)]
     L.mfx_trainer_create_layout.argtypes = [vp, vp, ll, i32, i32, C.POINTER(Options), vp, vp, C.POINTER(vp)]
+    L.mfx_triplets_to_device.argtypes = [vp, ll, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32)]
+    L.mfx_device_free.argtypes = [vp]
+    L.mfx_device_free.restype = None
     L.mfx_trainer_destroy.argtypes = [vp]
     L.mfx_trainer_destroy.restype = None
     L.mfx_trainer_bind_model.argtypes = [vp, vp, vp, vp, vp]
@@ -214,6 +217,20 @@ def rmse_array(model, R):
     out = C.c_double()
     _check(lib().mfx_rmse_array(mdl.ctypes.data, len(mdl), R.ctypes.data, len(R), C.byref(out)))
     return out.value
+
+
+def triplets_to_device(triplets, device=-1):
+    """mfx_triplets_to_device: float (u, v, r) triples on the host -> (device pointer of the node array, m, n).
+    Release the pointer with device_free()."""
+    t = np.ascontiguousarray(triplets, dtype=np.float32).reshape(-1)
+    assert t.size % 3 == 0
+    p, m, n = C.c_void_p(), C.c_int(), C.c_int()
+    _check(lib().mfx_triplets_to_device(t.ctypes.data, t.size // 3, device, C.byref(p), C.byref(m), C.byref(n)))
+    return p.value, m.value, n.value
+
+
+def device_free(ptr):
+    lib().mfx_device_free(ptr)
 
 
 # ---- epoch-level device API ------------------------------------------------------------------

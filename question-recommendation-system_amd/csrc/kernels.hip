@@ -750,6 +750,43 @@ hipError_t launch_fill(float *p, long long n, float v, int grid, hipStream_t s)
     return hipGetLastError();
 }
 
+// read_triplet (reference mf/mf.cpp:3367-3394) on the device: (u, v, r) float triples -> nodes, with
+// m = max u + 1, n = max v + 1 and a flag for negative ids
+__global__ __launch_bounds__(256) void triplets_kernel(const float *tri, long long count, SynthNode *out, int *mn_bad)
+{
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nth = (long long)gridDim.x * blockDim.x;
+    int mx = 0, nx = 0, bad = 0;
+    for (long long j = tid; j < count; j += nth) {
+        SynthNode nd;
+        nd.u = (int)tri[3 * j];
+        nd.v = (int)tri[3 * j + 1];
+        nd.r = tri[3 * j + 2];
+        bad |= (nd.u < 0) | (nd.v < 0);
+        mx = nd.u + 1 > mx ? nd.u + 1 : mx;
+        nx = nd.v + 1 > nx ? nd.v + 1 : nx;
+        out[j] = nd;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int a = __shfl_down(mx, off), b = __shfl_down(nx, off);
+        mx = a > mx ? a : mx;
+        nx = b > nx ? b : nx;
+        bad |= __shfl_down(bad, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&mn_bad[0], mx);
+        atomicMax(&mn_bad[1], nx);
+        if (bad) atomicOr(&mn_bad[2], 1);
+    }
+}
+
+hipError_t launch_triplets(const float *tri, long long count, void *out, int *mn_bad, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(triplets_kernel, dim3(grid), dim3(256), 0, s, tri, count, (SynthNode *)out, mn_bad);
+    return hipGetLastError();
+}
+
 hipError_t launch_synth(unsigned long long seed, unsigned long long shard, long long first,
                         long long count, int m, int n, void *out, int grid, hipStream_t s)
 {

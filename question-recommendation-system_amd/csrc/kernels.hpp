@@ -53,6 +53,7 @@ hipError_t launch_sq_err_nodes(const float *model, int m, int n, int k, float b,
 hipError_t launch_export(const float *rows, const int *map, int nrows, int k, int ka, float f,
                          int do_scale, float *out, int grid, hipStream_t s);
 hipError_t launch_fill(float *p, long long n, float v, int grid, hipStream_t s);
+hipError_t launch_triplets(const float *tri, long long count, void *out, int *mn_bad, int grid, hipStream_t s);
 hipError_t launch_synth(unsigned long long seed, unsigned long long shard, long long first,
                         long long count, int m, int n, void *out, int grid, hipStream_t s);
 

@@ -80,7 +80,10 @@ bool check_parameter(const mf_parameter &param)
 }
 
 // Train on the device and export the facade array; returns 0 or an mfx_status.
-int train_to_array(const mf_problem *tr, const mf_parameter &param, std::vector<float> &arr)
+// R_dev: the ratings as nodes in HBM (mfx_triplets_to_device) instead of tr->R.
+// out_malloc: export straight into a malloc'd array (*out_malloc, *out_len) instead of `arr`.
+int train_to_array(const mf_problem *tr, const mf_parameter &param, std::vector<float> &arr,
+                   const void *R_dev = nullptr, float **out_malloc = nullptr, long long *out_len = nullptr)
 {
     mfx_options opt;
     mfx_default_options(&opt);
@@ -90,7 +93,8 @@ int train_to_array(const mf_problem *tr, const mf_parameter &param, std::vector<
     opt.eta = param.eta;
 
     mfx_trainer *t = nullptr;
-    int rc = mfx_trainer_create((const mfx_node *)tr->R, tr->nnz, tr->m, tr->n, &opt, &t);
+    int rc = R_dev ? mfx_trainer_create_device(R_dev, tr->nnz, tr->m, tr->n, &opt, &t)
+                   : mfx_trainer_create((const mfx_node *)tr->R, tr->nnz, tr->m, tr->n, &opt, &t);
     if (rc != MFX_OK) return rc;
     struct Guard {
         mfx_trainer *t;
@@ -117,6 +121,18 @@ int train_to_array(const mf_problem *tr, const mf_parameter &param, std::vector<
         }
     }
     long long len = 5 + ((long long)info.m + info.n) * info.k;
+    if (out_malloc) {
+        float *buf = (float *)malloc(sizeof(float) * (size_t)len); // caller frees with free()
+        if (!buf) return MFX_E_NOMEM;
+        rc = mfx_trainer_export(t, buf, len);
+        if (rc != MFX_OK) {
+            free(buf);
+            return rc;
+        }
+        *out_malloc = buf;
+        *out_len = len;
+        return MFX_OK;
+    }
     arr.resize((size_t)len);
     return mfx_trainer_export(t, arr.data(), len);
 }
@@ -254,45 +270,25 @@ float *utility_train(float *train_data, int train_triplet_num, double p_l2, doub
     lens = 0;
     try {
         if (train_data == nullptr || train_triplet_num <= 0) return nullptr;
-        // read_triplet, reference mf/mf.cpp:3367-3394 (64-bit index: no overflow past 715 M),
-        // converted by a few host threads
-        std::vector<mf_node> R((size_t)train_triplet_num);
+        // read_triplet, reference mf/mf.cpp:3367-3394, on the device: the float triples are uploaded once and
+        // become nodes in HBM (64-bit index: no overflow past 715 M); m, n = largest ids + 1
         mf_problem tr;
         tr.m = 0;
         tr.n = 0;
         tr.nnz = train_triplet_num;
+        tr.R = nullptr;
+        void *dR = nullptr;
         {
-            const long long N = train_triplet_num;
-            unsigned hc = std::thread::hardware_concurrency();
-            const int nt = (int)std::max<long long>(1, std::min<long long>(hc ? hc : 1, N / 262144 + 1));
-            std::vector<int> mm(nt, 0), nn(nt, 0), neg(nt, 0);
-            std::vector<std::thread> pool;
-            for (int ti = 0; ti < nt; ++ti)
-                pool.emplace_back([&, ti]() {
-                    const long long lo = N * ti / nt, hi = N * (ti + 1) / nt;
-                    int mx = 0, nx = 0, bad = 0;
-                    for (long long j = lo; j < hi; ++j) {
-                        mf_node nd;
-                        nd.u = (mf_int)train_data[3 * j];
-                        nd.v = (mf_int)train_data[3 * j + 1];
-                        nd.r = train_data[3 * j + 2];
-                        bad |= (nd.u < 0) | (nd.v < 0);
-                        if (nd.u + 1 > mx) mx = nd.u + 1;
-                        if (nd.v + 1 > nx) nx = nd.v + 1;
-                        R[(size_t)j] = nd;
-                    }
-                    mm[ti] = mx;
-                    nn[ti] = nx;
-                    neg[ti] = bad;
-                });
-            for (auto &th : pool) th.join();
-            for (int ti = 0; ti < nt; ++ti) {
-                if (neg[ti]) return nullptr;
-                tr.m = std::max(tr.m, mm[ti]);
-                tr.n = std::max(tr.n, nn[ti]);
+            std::lock_guard<std::mutex> lock(g_gpu_mutex);
+            if (mfx_triplets_to_device(train_data, train_triplet_num, -1, &dR, &tr.m, &tr.n) != MFX_OK) {
+                std::cerr << "utility_train: " << mfx_last_error() << std::endl;
+                return nullptr;
             }
         }
-        tr.R = R.data();
+        struct FreeDev {
+            void *p;
+            ~FreeDev() { mfx_device_free(p); }
+        } free_dr{dR};
 
         mf_parameter param = mf_get_default_param(); // reference mf/mf.cpp:3508-3513
         param.lambda_p2 = (mf_float)p_l2;
@@ -305,19 +301,18 @@ float *utility_train(float *train_data, int train_triplet_num, double p_l2, doub
         long long total = 5 + ((long long)tr.m + tr.n) * (long long)k;
         if (total > 2147483647LL) return nullptr; // lens is an int (reference mf/mf.cpp:3424-3425)
 
-        std::vector<float> arr;
+        std::vector<float> unused;
+        float *result = nullptr; // caller frees with free() (reference model_to_array, mf/mf.cpp:3426)
+        long long len = 0;
         {
             std::lock_guard<std::mutex> lock(g_gpu_mutex);
-            int rc = train_to_array(&tr, param, arr);
+            int rc = train_to_array(&tr, param, unused, dR, &result, &len);
             if (rc != MFX_OK) {
                 std::cerr << "utility_train: " << mfx_last_error() << std::endl;
                 return nullptr;
             }
         }
-        float *result = (float *)malloc(sizeof(float) * arr.size()); // caller frees with free()
-        if (!result) return nullptr;
-        memcpy(result, arr.data(), sizeof(float) * arr.size());
-        lens = (int)arr.size();
+        lens = (int)len;
         return result;
     } catch (const std::exception &e) {
         std::cerr << e.what() << std::endl;

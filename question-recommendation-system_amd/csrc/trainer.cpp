@@ -1041,6 +1041,46 @@ int mfx_synth_host(unsigned long long seed, unsigned long long shard, long long 
     return MFX_OK;
 }
 
+int mfx_triplets_to_device(const float *triplets, long long count, int device, void **d_nodes, int *m, int *n)
+{
+    if (!triplets || count <= 0 || !d_nodes || !m || !n) return fail(MFX_E_ARG, "bad argument");
+    *d_nodes = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(MFX_E_HIP, "no HIP device: the MI355X path cannot run (there is no CPU fallback)");
+    if (device >= ndev) return fail(MFX_E_ARG, "device ordinal out of range");
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    DevBuf<float> dTri;
+    DevBuf<int> dMn;
+    void *nodes = nullptr;
+    HIP_TRY(dTri.alloc((size_t)count * 3));
+    HIP_TRY(dMn.alloc(3));
+    HIP_TRY(hipMalloc(&nodes, (size_t)count * sizeof(mfx_node)));
+    int mn[3] = {0, 0, 0};
+    hipError_t e = hipMemcpy(dTri.p, triplets, (size_t)count * 3 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(dMn.p, 0, sizeof(mn));
+    if (e == hipSuccess) e = mfx::launch_triplets(dTri.p, count, nodes, dMn.p, grid_for(count, prop.multiProcessorCount), nullptr);
+    if (e == hipSuccess) e = hipMemcpy(mn, dMn.p, sizeof(mn), hipMemcpyDeviceToHost);
+    if (e != hipSuccess || mn[2]) {
+        (void)hipFree(nodes);
+        if (e != hipSuccess) return fail(MFX_E_HIP, hipGetErrorString(e));
+        return fail(MFX_E_ARG, "negative id in the triplets");
+    }
+    *d_nodes = nodes;
+    *m = mn[0];
+    *n = mn[1];
+    return MFX_OK;
+}
+
+void mfx_device_free(void *p)
+{
+    if (p) (void)hipFree(p);
+}
+
 int mfx_synth_device(unsigned long long seed, unsigned long long shard, long long first,
                      long long count, int m, int n, void *out_dev, void *stream)
 {

@@ -254,6 +254,27 @@ def test_config2_full_size(pkg):
     assert abs(rm - 0.94767) / 0.94767 < 0.03, rm        # observed 0.925-0.928: the GPU path is slightly ahead
 
 
+def test_triplets_to_device_matches_read_triplet(pkg):
+    """mfx_triplets_to_device (read_triplet on the device, mf.cpp:3367-3394): same nodes, m, n as the host conversion;
+    a trainer built from the device array equals one built from the host nodes; negative ids fail loudly."""
+    rng = np.random.default_rng(5)
+    m, n, nnz = 700, 900, 50000
+    tri = np.stack([rng.integers(0, m, nnz), rng.integers(0, n, nnz), rng.uniform(1, 5, nnz)], 1).astype(np.float32)
+    tri[0, :2] = (m - 1, n - 1)
+    ptr, dm, dn = pkg.triplets_to_device(tri)
+    assert (dm, dn) == (m, n)
+    R = pkg.as_nodes(tri[:, 0].astype(np.int32), tri[:, 1].astype(np.int32), tri[:, 2])
+    a = pkg.Trainer(None, m, n, opts=pkg.default_options(k=16), device_ptr=ptr, nnz=nnz)
+    b = pkg.Trainer(R, m, n, k=16)
+    ea, ta, sa = a.plan_copy(); eb, tb, sb = b.plan_copy()
+    assert np.array_equal(ea, eb) and np.array_equal(ta, tb) and np.array_equal(sa, sb)
+    a.close(); b.close(); pkg.device_free(ptr)
+    bad = tri.copy(); bad[7, 1] = -3
+    with pytest.raises(pkg.MfxError):
+        pkg.triplets_to_device(bad)
+    assert pkg.utility_train(bad, 0.1, 0.1, 8, 3, 0.1) is None  # the facade returns NULL, as for any bad input
+
+
 def test_shared_layout_from_common_counts(pkg, orc):
     """mfx_trainer_create_layout: trainers over different parts of one problem that are given the same row
     counts place every id in the same row (what lets the stripe trainers of a rank share P and a Q stripe
