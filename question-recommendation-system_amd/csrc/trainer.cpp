@@ -95,9 +95,10 @@ struct mfx_trainer {
     DevBuf<mfx::EntryD> dEntries;
     DevBuf<mfx::TaskDescD> dTasks;
     DevBuf<long long> dSlotPtr;
-    DevBuf<int> dSlotState; // per round: cursor[ns]
+    DevBuf<double> dEpochState; // zeroed once per epoch: LOSS_SLOTS loss sums, then the ns*ns task cursors
+    int *dSlotStateP = nullptr;  // -> the cursors inside dEpochState
     DevBuf<double> dScalars; // [0..3] scratch for metrics
-    DevBuf<double> dLoss;    // LOSS_SLOTS partial sums of the epoch's online loss
+    double *dLossP = nullptr;    // -> the loss sums inside dEpochState
     DevBuf<int> dOwnBegin, dGatBegin; // RoundArgs::own_begin / gat_begin (ns+1 each)
     DevBuf<int> dOmegaP, dOmegaQ, dPmap, dQmap;
     DevBuf<float> oP, oQ, oPG, oQG; // owned factor storage
@@ -339,10 +340,12 @@ static int create_impl(const mfx::Node *R, const void *R_dev, long long nnz, int
         else HIP_TRY(t->dEntries.alloc(p.entries.size()));
         HIP_TRY(t->dTasks.alloc(p.tasks.size()));
         HIP_TRY(t->dSlotPtr.alloc(p.slot_task_ptr.size()));
-        HIP_TRY(t->dSlotState.alloc((size_t)p.ns * p.ns));
+        const size_t epoch_state_doubles = mfx::LOSS_SLOTS + ((size_t)p.ns * p.ns + 1) / 2;
+        HIP_TRY(t->dEpochState.alloc(epoch_state_doubles));
+        HIP_TRY(hipMemset(t->dEpochState.p, 0, epoch_state_doubles * sizeof(double)));
+        t->dLossP = t->dEpochState.p;
+        t->dSlotStateP = (int *)(t->dEpochState.p + mfx::LOSS_SLOTS);
         HIP_TRY(t->dScalars.alloc(4));
-        HIP_TRY(t->dLoss.alloc(mfx::LOSS_SLOTS));
-        HIP_TRY(hipMemset(t->dLoss.p, 0, mfx::LOSS_SLOTS * sizeof(double)));
         {
             // stripe boundaries for the kernel (buffer descriptors over the gathered stripe, L2 warm-up)
             const std::vector<int> &ob = p.owner_is_q ? p.q_begin : p.p_begin, &gb = p.owner_is_q ? p.p_begin : p.q_begin;
@@ -531,8 +534,8 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
     if (nparts < 1 || nparts > ns || part < 0 || part >= nparts)
         return fail(MFX_E_ARG, "epoch part out of range (1 <= nparts <= stripes)");
     if (part == 0) {
-        HIP_TRY(hipMemsetAsync(t->dSlotState.p, 0, (size_t)ns * ns * sizeof(int), s));
-        HIP_TRY(hipMemsetAsync(t->dLoss.p, 0, mfx::LOSS_SLOTS * sizeof(double), s));
+        // one fill for the loss sums and the task cursors (they share a buffer)
+        HIP_TRY(hipMemsetAsync(t->dEpochState.p, 0, (mfx::LOSS_SLOTS + ((size_t)ns * ns + 1) / 2) * sizeof(double), s));
     }
 
     mfx::RoundArgs a;
@@ -542,7 +545,7 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
     a.gat_acc = p.owner_is_q ? t->dPG : t->dQG;
     a.entries = t->dEntries.p;
     a.tasks = t->dTasks.p;
-    a.loss = t->dLoss.p;
+    a.loss = t->dLossP;
     a.own_begin = t->dOwnBegin.p;
     a.gat_begin = t->dGatBegin.p;
     a.lambda_own = p.owner_is_q ? t->lambda_q : t->lambda_p;
@@ -626,7 +629,7 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
         const int r = (int)((i + t->epochs_done) % ns); // rotate the starting round per epoch
         a.round = r;
         a.slot_task_ptr = t->dSlotPtr.p + (size_t)r * ns;
-        a.slot_cursor = t->dSlotState.p + (size_t)r * ns;
+        a.slot_cursor = t->dSlotStateP + (size_t)r * ns;
         HIP_TRY(mfx::launch_sgd_round(p.lanes, a, grid, s));
     }
     if (e1) {
@@ -652,7 +655,7 @@ static int verify_rounds(mfx_trainer *t)
     if (!t->loss_pending) return MFX_OK;
     const mfx::Plan &p = t->plan;
     std::vector<int> cur((size_t)p.ns * p.ns);
-    HIP_TRY(hipMemcpy(cur.data(), t->dSlotState.p, cur.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cur.data(), t->dSlotStateP, cur.size() * sizeof(int), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < cur.size(); ++i)
         if (cur[i] < p.slot_task_ptr[i + 1] - p.slot_task_ptr[i])
             return fail(MFX_E_STATE, "a stripe block was left unprocessed: workgroup-to-XCD placement "
@@ -675,7 +678,7 @@ int mfx_trainer_last_loss(mfx_trainer *t, double *sum_sq)
     HIP_TRY(hipSetDevice(t->device));
     HIP_TRY(hipDeviceSynchronize());
     double part[mfx::LOSS_SLOTS];
-    HIP_TRY(hipMemcpy(part, t->dLoss.p, sizeof(part), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(part, t->dLossP, sizeof(part), hipMemcpyDeviceToHost));
     t->last_loss = 0;
     for (int i = 0; i < mfx::LOSS_SLOTS; ++i) t->last_loss += part[i];
     *sum_sq = t->last_loss;
