@@ -1,27 +1,38 @@
 #!/usr/bin/env python3
 """bench.py -- ratings/s per SGD epoch of the MI355X matrix-factorisation trainer.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus N --steps K --warmup W [--config c2|c1]
+  (N > 1 without a launcher: bench.py starts the N ranks itself through torch.distributed.run;
+   under a launcher -- WORLD_SIZE set -- it is one of the ranks.)
 
-One "step" = one full-k SGD epoch (the per-rating loop of reference mf/mf.cpp:1201-1238 over
-every rating) on BASELINE.json configs[1]: synthetic 100k x 50k, 10 M ratings, k = 32, generated
-in HBM.  With N GPUs each rank trains its own 100k-user shard of an (N*100k) x 50k problem
-(weak scaling).  The item factors Q are shared over RCCL inside the timed region: by default item
-stripes of Q rotate round the ring of ranks (one writer per row, exact SGD -- multi.py); --combine avg
-selects BASELINE.json's replicate-and-average instead (measured to lose the fit).
-Epoch 0 (slow_only, 8 of k factors) and the one-off pre-processing are outside the timed region, as
-in SURVEY.md 8(d).
+One "step" = one full-k SGD epoch (the per-rating loop of reference mf/mf.cpp:1201-1238 over every
+rating) with ratings, layout and factors resident in HBM.  Workload (config.workload names it):
+
+  c2 (default)  BASELINE.json configs[2]: synthetic 1M x 500k, 100 M ratings, k = 64 -- the largest
+                single-GPU configuration.  The line also carries a "configs1" block (configs[1]:
+                100k x 50k, 10 M ratings, k = 32) measured in the same run (N = 1 only).
+  c1            configs[1] alone.
+
+With N GPUs each rank trains its own user shard of an (N*m) x n problem (weak scaling, configs[2] per
+GPU); item slots of Q travel round the ring of ranks over RCCL inside the timed region (one writer per
+row, exact SGD -- multi.py); --combine avg selects BASELINE.json's replicate-and-average instead
+(measured to lose the fit).  Epoch 0 (slow_only, 8 of k factors) and the one-off
+pre-processing are outside the timed region, as in SURVEY.md 8(d).
 
 Prints ONE JSON line (rank 0): metric/value/unit per the driver contract, plus
-  roofline     -- algorithmic HBM bytes per launch / mean launch time (HIP events) vs 8 TB/s
-  cpu_baseline -- the reference CPU trainer (oracle/_ref) or, if absent, the oracle port,
-                  timed on this host by the iteration-delta method (rank 0, N = 1 only)
+  roofline        algorithmic bytes per launch / mean launch time (HIP events on the launch stream) vs 8 TB/s;
+                  `traffic` = measured bytes per launch between the L2s and the fabric (rocprofv3 PMC passes of
+                  this command, profiles/), and the `l2` block, so a reader sees which level binds
+  rounds_verified every block of every timed launch was worked (mfx_trainer_sync's cursor check)
+  matched_rmse    GPU vs the deterministic oracle vs the reference CPU trainer after the SAME number of epochs
+  cpu_baseline    the reference CPU trainer (oracle/_ref) on a bounded sample of the workload, timed on this
+                  host by the iteration-delta method (rank 0, N = 1 only)
 """
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,69 +42,196 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
-WORKLOAD = dict(m=100000, n=50000, nnz=10000000, k=32, lambda_p=0.1, lambda_q=0.1, eta=0.1, seed=1)
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CONFIGS = {
+    "c1": dict(name="BASELINE configs[1]", m=100000, n=50000, nnz=10000000, k=32),
+    "c2": dict(name="BASELINE configs[2]", m=1000000, n=500000, nnz=100000000, k=64),
+}
+HYPER = dict(lambda_p=0.1, lambda_q=0.1, eta=0.1, seed=1)  # utility_train defaults (mf.cpp:4549-4551)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L2_PEAK_GBS = 34500.0   # MI355X_MICROARCH.md: aggregate L2 bandwidth
+RMSE_RTOL = 0.02        # the stated parity tolerance (README / DESIGN.md 5)
+MATCH_EPOCHS = 12       # epoch count of the matched-RMSE legs (= T(n2) of the CPU timing)
+SAMPLE_NNZ = 20000000   # cpu_baseline sample: the first 20 M ratings of the workload's stream
 
 
-def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
-    command (profiles/r*_pmc_summary.txt; FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md, both in KiB).
+def golden_full_size():
+    """Oracle values at full size (tests/golden/full_size.json, made by tests/golden/make_full_size.py)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "full_size.json")))
+    except Exception:
+        return {}
+
+
+def measured_counters(cfg_name):
+    """Per-launch counters of the dominant kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/r*_pmc_<cfg>.json, written by scripts/summarize_pmc.py from separate --pmc passes).
     bench.py cannot collect counters itself; None when no summary is present."""
     import glob
-    import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.txt")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % cfg_name)))
     if not files:
         return None
-    txt = open(files[-1]).read()
-    f = re.search(r"FETCH_SIZE:.*last half ([0-9.]+)", txt)
-    w = re.search(r"WRITE_SIZE:.*last half ([0-9.]+)", txt)
-    if not f or not w:
+    try:
+        d = json.load(open(files[-1]))
+        d["source"] = os.path.relpath(files[-1], ROOT)
+        return d
+    except Exception:
         return None
-    return (2.0 * float(f.group(1)) + float(w.group(1))) * 1024.0
 
 
-def cpu_baseline(pkg, w, budget_s=25.0):
-    """Reference CPU epoch rate on this host (iteration-delta)."""
+def effective_cores():
+    """Cores this process may really use: affinity mask and cgroup CPU quota, whichever is smaller."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(pkg, cfg, budget_s=60.0):
+    """Reference CPU epoch rate on this host (iteration-delta) on a bounded sample."""
     orc = ge.import_oracle()
-    cores = os.cpu_count() or 1
-    m, n, k = w["m"], w["n"], w["k"]
-    if orc.have_ref():
-        R = pkg.synth_host(w["seed"], 0, w["nnz"], m, n)
-        threads, bins = 12, 20  # the facade's hard-wired values (reference mf/mf.cpp:4544-4545)
-        n1, n2 = 2, 12
-        best = None
-        t_start = time.time()
-        for _ in range(3):
-            # each call runs in a killable child: the reference's shutdown race (quirk Q2)
-            # must never cost the bench line
-            t1, _r = orc.ref_time_train(R, m, n, k, n1, threads, bins, timeout=90)
-            t2, rm = orc.ref_time_train(R, m, n, k, n2, threads, bins, timeout=90)
-            per_epoch = (t2 - t1) / (n2 - n1)
-            if per_epoch > 0 and (best is None or per_epoch < best[0]):
-                best = (per_epoch, rm)
-            if time.time() - t_start > budget_s:
-                break
-        out = {"value": len(R) / best[0], "unit": "ratings/s", "cores": min(threads, cores),
-               "kind": "reference", "threads": threads, "bins": threads and bins, "host_cores": cores,
-               "rmse_after_%d_epochs" % n2: best[1],
-               "sample": "full workload (10M ratings), mf_train quiet, T(%d it)-T(%d it), min of <=3" % (n2, n1)}
-        # all-core leg (nr_bins = max(20, 2*threads+1), reference mf/mf.cpp:3142,3177-3181)
-        if time.time() - t_start < budget_s and cores > threads:
-            th = min(cores, 64)
-            bn = max(20, 2 * th + 1)
-            t1, _r = orc.ref_time_train(R, m, n, k, n1, th, bn, timeout=90)
-            t2, _r = orc.ref_time_train(R, m, n, k, n2, th, bn, timeout=90)
-            if t2 > t1:
-                out["value_allcores"] = len(R) * (n2 - n1) / (t2 - t1)
-                out["allcores_threads"] = th
-        return out
-    # port: one-thread restatement on a 2M-rating sample of the same stream
-    ns = 2000000
-    R = pkg.synth_host(w["seed"], 0, ns, m, n)
-    t0 = time.time(); orc.train(R, m, n, k=k, iters=2); t1 = time.time() - t0
-    t0 = time.time(); orc.train(R, m, n, k=k, iters=6); t2 = time.time() - t0
-    return {"value": ns * 4 / max(t2 - t1, 1e-9), "unit": "ratings/s", "cores": 1, "kind": "port",
-            "host_cores": cores, "sample": "first 2M ratings of the workload, oracle C port, T(6 it)-T(2 it)"}
+    cores, eff = os.cpu_count() or 1, effective_cores()
+    m, n, k = cfg["m"], cfg["n"], cfg["k"]
+    ns = min(SAMPLE_NNZ, cfg["nnz"])
+    R = pkg.synth_host(HYPER["seed"], 0, ns, m, n)
+    sample = "first %d ratings of the workload's stream (full %dx%d id space, k=%d)" % (ns, m, n, k)
+    if not orc.have_ref():
+        # port: one-thread restatement on a 2M-rating prefix
+        ns = 2000000
+        R = R[:ns]
+        t0 = time.time(); orc.train(R, m, n, k=k, iters=2); t1 = time.time() - t0
+        t0 = time.time(); orc.train(R, m, n, k=k, iters=6); t2 = time.time() - t0
+        return {"value": ns * 4 / max(t2 - t1, 1e-9), "unit": "ratings/s", "cores": 1, "kind": "port",
+                "host_cores": cores, "cpu_model": cpu_model(),
+                "sample": "first 2M ratings of the workload's stream, oracle C port, T(6 it)-T(2 it)"}, None
+    t_start = time.time()
+    n1, n2 = 2, MATCH_EPOCHS
+    tmo = 240
+
+    def delta(threads, bins, a, b):
+        # each call runs in a killable child: the reference's shutdown race (quirk Q2) must never cost the line
+        ta, _r = orc.ref_time_train(R, m, n, k, a, threads, bins, timeout=tmo)
+        tb, rm = orc.ref_time_train(R, m, n, k, b, threads, bins, timeout=tmo)
+        return (tb - ta) / (b - a), rm
+
+    # (i) the facade's hard-wired setting (reference mf/mf.cpp:4544-4545); its T(n2) run is the matched-RMSE leg
+    per, rm = delta(12, 20, n1, n2)
+    legs = [{"threads": 12, "bins": 20, "ratings_per_s": ns / per if per > 0 else None, "epochs": [n1, n2]}]
+    # (ii) short sweep for the reference's best point on this host: nr_bins = max(20, 2*threads+1)
+    # (reference mf/mf.cpp:3142, 3177-3181); thread counts up to the cores this process may use
+    for th in (8, 16, 24, 32, 48):
+        if th > eff or time.time() - t_start > budget_s:
+            continue
+        try:
+            p2, _ = delta(th, max(20, 2 * th + 1), n1, 7)
+            legs.append({"threads": th, "bins": max(20, 2 * th + 1), "ratings_per_s": ns / p2 if p2 > 0 else None, "epochs": [n1, 7]})
+        except Exception as e:
+            legs.append({"threads": th, "error": repr(e)[:200]})
+    ok = [l for l in legs if l.get("ratings_per_s")]
+    best = max(ok, key=lambda l: l["ratings_per_s"])
+    out = {"value": best["ratings_per_s"], "unit": "ratings/s", "cores": best["threads"], "kind": "reference",
+           "threads": best["threads"], "bins": best["bins"], "host_cores": cores, "usable_cores": eff,
+           "cpu_model": cpu_model(), "facade_12_threads_20_bins": legs[0]["ratings_per_s"], "sweep": legs,
+           "rmse_after_%d_epochs" % n2: rm,
+           "sample": sample + "; mf_train quiet, T(n2 it)-T(n1 it) per leg; value = best leg of the sweep"}
+    return out, (R, rm)
+
+
+def train_rmse(pkg, torch, dev, R_ptr, nnz, m, n, k, epochs, stream):
+    """GPU training RMSE (calc_rmse formula) after `epochs` epochs (epoch 0 slow_only) on ratings in HBM."""
+    opts = pkg.default_options(k=k, lambda_p2=HYPER["lambda_p"], lambda_q2=HYPER["lambda_q"], eta=HYPER["eta"], device=dev.index)
+    t = pkg.Trainer(None, m, n, opts=opts, device_ptr=R_ptr, nnz=nnz)
+    t.init_model()
+    tr = []
+    for it in range(epochs):
+        t.epoch(slow_only=(it == 0), stream=stream)
+        tr.append(float(np.sqrt(t.last_loss() / nnz) * t.info.scale))
+    rm = t.rmse()
+    t.close()
+    return rm, tr
+
+
+def run_single(pkg, torch, dev, cfg, steps, warmup, stream):
+    """N = 1: time `steps` full-k epochs of one config; returns the measurements."""
+    m, n, nnz, k = cfg["m"], cfg["n"], cfg["nnz"], cfg["k"]
+    R_dev = torch.empty(nnz * 3, dtype=torch.int32, device=dev)
+    pkg.synth_device(HYPER["seed"], 0, nnz, m, n, R_dev.data_ptr(), None, shard=0)
+    torch.cuda.synchronize()
+    opts = pkg.default_options(k=k, lambda_p2=HYPER["lambda_p"], lambda_q2=HYPER["lambda_q"], eta=HYPER["eta"], device=dev.index)
+    t = pkg.Trainer(None, m, n, opts=opts, device_ptr=R_dev.data_ptr(), nnz=nnz)
+    info = t.info
+    t.init_model()
+    t.epoch(slow_only=True, stream=stream)  # the reference's epoch 0 (8 of k factors): not part of the metric
+    for _ in range(warmup):
+        t.epoch(stream=stream)
+    torch.cuda.synchronize()
+    t.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t.epoch(stream=stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t.sync()  # raises if any block of any launch was left unworked (cursor check, sticky across epochs)
+    launches, kern_ms = t.timing_read()
+    t.timing_enable(False)
+    rmse = t.rmse()
+    t.close()
+    return dict(R_dev=R_dev, info=info, elapsed=elapsed, launches=launches, kern_ms=kern_ms, final_rmse=rmse,
+                epochs_trained=1 + warmup + steps)
+
+
+def roofline_block(cfg_name, info, nnz, steps, launches, launch_s, timing_note):
+    bytes_per_launch = info.bytes_per_rating * nnz * steps / max(launches, 1)
+    achieved = bytes_per_launch / launch_s / 1e9
+    rl = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+          "traffic": None,
+          "algorithmic_bytes_per_launch": bytes_per_launch, "kernel": "sgd_round<%d>" % info.lanes_per_rating,
+          "bytes_per_rating": info.bytes_per_rating, "ratings_per_launch": nnz * steps / max(launches, 1),
+          "avg_launch_us": launch_s * 1e6, "launches_timed": launches, "timing": timing_note,
+          "note": "achieved/frac are ALGORITHMIC bytes (16*k_a+44 per rating, SURVEY.md 8d) over time: owner rows kept in "
+                  "registers and L2/Infinity-Cache hits never reach the fabric, so frac can exceed 1 and is not a "
+                  "fraction of HBM traffic -- traffic_frac is"}
+    pmc = measured_counters(cfg_name)
+    if pmc:
+        rl["traffic"] = pmc.get("traffic_bytes_per_launch")
+        rl["traffic_unit"] = "bytes per launch between the L2s and the fabric (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC, %s)" % pmc["source"]
+        if rl["traffic"]:
+            rl["traffic_GBs"] = rl["traffic"] / launch_s / 1e9
+            rl["traffic_frac"] = rl["traffic_GBs"] / HBM_PEAK_GBS
+        if pmc.get("l2_requests_per_launch"):
+            l2b = pmc["l2_requests_per_launch"] * 128.0
+            rl["l2"] = {"requests_per_launch": pmc["l2_requests_per_launch"], "hit_rate": pmc.get("l2_hit_rate"),
+                        "bytes_per_launch_at_128B": l2b, "achieved": l2b / launch_s / 1e9, "peak": L2_PEAK_GBS,
+                        "unit": "GB/s", "frac": l2b / launch_s / 1e9 / L2_PEAK_GBS}
+    return rl
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start the N ranks as fresh children (this parent never touches the GPU)."""
+    import torch
+    have = torch.cuda.device_count()  # does not initialise the device on this image
+    if have < args.gpus and not args.same_device:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (a 1-GPU result would not be a --gpus %d result)"
+                         % (args.gpus, have, args.gpus))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -101,25 +239,32 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=os.environ.get("MFX_BENCH_CONFIG", "c2"), choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--nnz", type=int, default=WORKLOAD["nnz"], help=argparse.SUPPRESS)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] block and the matched-RMSE legs")
+    ap.add_argument("--nnz", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)  # "gloo": rehearsal of N>1 on one GPU
     ap.add_argument("--same-device", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--combine", default=os.environ.get("MFX_COMBINE", "rotate"),
-                    help="how the item factors Q are shared when N>1: rotate (item stripes travel round the ring of "
+                    help="how the item factors Q are shared when N>1: rotate (item slots travel round the ring of "
                          "ranks, one writer per row: exact SGD) | avg (replicas averaged by all-reduce)")
+    ap.add_argument("--slots-per-rank", type=int, default=int(os.environ.get("MFX_SLOTS_PER_RANK", "2")),
+                    help="rotate: item slots per rank (2 = the ring transfer runs under the next step's kernels)")
     ap.add_argument("--syncs-per-epoch", type=int, default=int(os.environ.get("MFX_SYNCS_PER_EPOCH", "1")),
-                    help="RCCL averaging points per epoch when N>1 (1..stripes)")
+                    help="avg: RCCL averaging points per epoch when N>1 (1..stripes)")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no HIP device visible)")
     if args.same_device:
@@ -128,8 +273,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     # One explicit stream for everything: the trainers' launches (handle passed to mfx_trainer_epoch) and the
     # RCCL calls torch makes on the current stream.  The default stream's handle is 0, which the C-ABI reads
-    # as "use the trainer's own stream" -- the stripe exchange would then not be ordered behind the kernels.
+    # as "use the trainer's own stream" -- the slot exchange would then not be ordered behind the kernels.
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+    stream = torch.cuda.current_stream().cuda_stream
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -138,36 +284,97 @@ def main():
             dist.init_process_group(args.backend)
 
     pkg = ge.import_package()
-    w = dict(WORKLOAD)
-    w["nnz"] = args.nnz
-    m, n, nnz, k = w["m"], w["n"], w["nnz"], w["k"]
+    cfg = dict(CONFIGS[args.config])
+    if args.nnz:
+        cfg["nnz"] = args.nnz
+    m, n, nnz, k = cfg["m"], cfg["n"], cfg["nnz"], cfg["k"]
+    workload = "%s: synthetic %dx%d, %d ratings, k=%d" % (cfg["name"], m, n, nnz, k)
 
-    # ratings of this rank's user shard, generated straight into HBM
+    if world == 1:
+        r = run_single(pkg, torch, dev, cfg, args.steps, args.warmup, stream)
+        info, elapsed = r["info"], r["elapsed"]
+        launch_s = r["kern_ms"] / 1e3 / max(r["launches"], 1)
+        note = ("HIP events bracket each epoch's launches on the launch stream; mean = bracket / launches "
+                "(inter-launch gaps included)")
+        out = {
+            "metric": "ratings/sec per SGD epoch", "value": nnz * args.steps / elapsed, "unit": "ratings/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "m_per_gpu": m, "n": n, "nnz_per_gpu": nnz, "k": k,
+                       "lambda": HYPER["lambda_p"], "eta": HYPER["eta"], "stripes": info.stripes, "combine": None},
+            "final_rmse": r["final_rmse"], "epochs_trained": r["epochs_trained"], "rounds_verified": True,
+            "rmse_rtol": RMSE_RTOL,
+            "roofline": roofline_block(args.config, info, nnz, args.steps, r["launches"], launch_s, note),
+        }
+        gold = golden_full_size()
+        if not args.no_secondary:
+            # matched RMSE on the full workload: same triples, same epoch count as the oracle fixture
+            g = gold.get(args.config if not args.nnz else "", {})
+            want = g.get("rmse_after", {}).get(str(MATCH_EPOCHS))
+            got, tr = train_rmse(pkg, torch, dev, r["R_dev"].data_ptr(), nnz, m, n, k, MATCH_EPOCHS, stream)
+            out["matched_rmse"] = {"epochs": MATCH_EPOCHS, "gpu": got, "oracle": want,
+                                   "rel_diff_vs_oracle": (got - want) / want if want else None,
+                                   "within_rtol": (abs(got - want) / want <= RMSE_RTOL) if want else None,
+                                   "gpu_tr_rmse": tr, "oracle_tr_rmse": g.get("tr_rmse"),
+                                   "oracle_source": "tests/golden/full_size.json (one-worker oracle on these exact triples)"}
+        if not args.no_cpu_baseline:
+            try:
+                base, keep = cpu_baseline(pkg, cfg)
+                out["cpu_baseline"] = base
+                if keep is not None and not args.no_secondary:
+                    # the SAME sample on the GPU for the SAME epochs, next to the reference's and the oracle's value
+                    Rs, ref_rm = keep
+                    ns = len(Rs)
+                    got, _ = train_rmse(pkg, torch, dev, r["R_dev"].data_ptr(), ns, m, n, k, MATCH_EPOCHS, stream)
+                    want = gold.get(args.config + "s", {}).get("rmse_after", {}).get(str(MATCH_EPOCHS)) if not args.nnz else None
+                    out["matched_rmse_sample"] = {"epochs": MATCH_EPOCHS, "nnz": ns, "gpu": got, "reference_cpu": ref_rm,
+                                                  "oracle": want,
+                                                  "rel_diff_vs_reference": (got - ref_rm) / ref_rm if ref_rm else None,
+                                                  "rel_diff_vs_oracle": (got - want) / want if want else None}
+            except Exception as e:  # the baseline is a report, never a reason to lose the line
+                out["cpu_baseline"] = {"value": None, "unit": "ratings/s", "cores": 0, "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        del r["R_dev"]
+        if args.config != "c1" and not args.no_secondary:
+            c1 = dict(CONFIGS["c1"])
+            r1 = run_single(pkg, torch, dev, c1, args.steps, args.warmup, stream)
+            l1 = r1["kern_ms"] / 1e3 / max(r1["launches"], 1)
+            g1 = gold.get("c1", {}).get("rmse_after", {}).get(str(MATCH_EPOCHS))
+            got1, _ = train_rmse(pkg, torch, dev, r1["R_dev"].data_ptr(), c1["nnz"], c1["m"], c1["n"], c1["k"], MATCH_EPOCHS, stream)
+            out["configs1"] = {"workload": "%s: synthetic %dx%d, %d ratings, k=%d" % (c1["name"], c1["m"], c1["n"], c1["nnz"], c1["k"]),
+                               "value": c1["nnz"] * args.steps / r1["elapsed"], "unit": "ratings/s",
+                               "ms_per_step": r1["elapsed"] / args.steps * 1e3, "rounds_verified": True,
+                               "roofline": roofline_block("c1", r1["info"], c1["nnz"], args.steps, r1["launches"], l1, note),
+                               "matched_rmse": {"epochs": MATCH_EPOCHS, "gpu": got1, "oracle": g1,
+                                                "rel_diff_vs_oracle": (got1 - g1) / g1 if g1 else None}}
+        print(json.dumps(out), flush=True)
+        return
+
+    # ---- N > 1: one rank of the job -------------------------------------------------------------------
     R_dev = torch.empty(nnz * 3, dtype=torch.int32, device=dev)
-    pkg.synth_device(w["seed"], 0, nnz, m, n, R_dev.data_ptr(), None, shard=rank)
+    pkg.synth_device(HYPER["seed"], 0, nnz, m, n, R_dev.data_ptr(), None, shard=rank)  # this rank's user shard
     torch.cuda.synchronize()
-
-    rotate = world > 1 and args.combine == "rotate"
+    rotate = args.combine == "rotate"
     if rotate:
         spec = __import__("importlib.util").util.spec_from_file_location("qrs_multi", os.path.join(ge.PKG_DIR, "multi.py"))
         multi = __import__("importlib.util").util.module_from_spec(spec)
         spec.loader.exec_module(multi)
-        R_host = R_dev.cpu().numpy().view(pkg.NODE).reshape(-1)  # plan building is host-side in this round
+        t = multi.RotatingTrainer(pkg, R_dev, m, n, world, rank, dist, dev, backend=args.backend,
+                                  slots_per_rank=args.slots_per_rank, k=k, lambda_p2=HYPER["lambda_p"],
+                                  lambda_q2=HYPER["lambda_q"], eta=HYPER["eta"], device=local_rank)
         del R_dev
-        t = multi.RotatingTrainer(pkg, R_host, m, n, world, rank, dist, dev, backend=args.backend, k=k,
-                                  lambda_p2=w["lambda_p"], lambda_q2=w["lambda_q"], eta=w["eta"], device=local_rank)
-        del R_host
         info = t.info
-        ka = info.k_aligned
-        stream = torch.cuda.current_stream().cuda_stream
-        nsync = world
+        nsync = t.S
 
         def epoch(slow=False):
             t.epoch(slow_only=slow, stream=stream)
+
+        def final_rmse():
+            return t.rmse(all_ranks=True)
     else:
         # (replicas that average Q need the same item layout on every rank: the data-independent one)
-        opts = pkg.default_options(k=k, lambda_p2=w["lambda_p"], lambda_q2=w["lambda_q"], eta=w["eta"],
-                                   device=local_rank, identity_maps=2 if world > 1 else 0)
+        opts = pkg.default_options(k=k, lambda_p2=HYPER["lambda_p"], lambda_q2=HYPER["lambda_q"], eta=HYPER["eta"],
+                                   device=local_rank, identity_maps=2)
         t = pkg.Trainer(None, m, n, opts=opts, device_ptr=R_dev.data_ptr(), nnz=nnz)
         del R_dev
         info = t.info
@@ -179,8 +386,7 @@ def main():
         QG = torch.empty(n * 2, dtype=torch.float32, device=dev)
         t.bind_model(P.data_ptr(), Q.data_ptr(), PG.data_ptr(), QG.data_ptr())
         t.init_model()  # same seed stream on every rank: Q starts identical everywhere
-        stream = torch.cuda.current_stream().cuda_stream
-        nsync = max(1, min(args.syncs_per_epoch, info.stripes)) if world > 1 else 1
+        nsync = max(1, min(args.syncs_per_epoch, info.stripes))
 
         def average_q():
             """--combine avg: replicated item factors, Q <- mean over ranks (summing the replicas' deltas
@@ -196,75 +402,54 @@ def main():
         def epoch(slow=False):
             for part in range(nsync):
                 t.epoch_part(part, nsync, slow_only=slow, stream=stream)
-                if world > 1:
-                    average_q()
+                average_q()
 
-    epoch(slow=True)  # the reference's epoch 0 (8 of k factors): not part of the metric
+        def final_rmse():
+            acc = torch.tensor([t.sq_err(), float(nnz)], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+            return float(np.sqrt(float(acc[0]) / float(acc[1])))
+
+    epoch(slow=True)
     for _ in range(args.warmup):
         epoch()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    dist.barrier()
     torch.cuda.synchronize()
     t.timing_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         epoch()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    t.sync()  # cursor check of every stripe trainer
     launches, kern_ms = t.timing_read()
     t.timing_enable(False)
-
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    rmse = t.rmse()
-    epochs_total = 1 + args.warmup + args.steps
-
+    rmse = final_rmse()
     if rank == 0:
-        value = world * nnz * args.steps / elapsed
-        bytes_per_launch = info.bytes_per_rating * nnz * args.steps / max(launches, 1)
-        avg_launch_s = kern_ms / 1e3 / max(launches, 1)
-        timing_note = ("HIP events bracket each epoch's launches on the launch stream; mean = bracket / launches "
-                       "(inter-launch gaps included)")
-        if rotate:  # several trainers share the stream: use this rank's wall clock (stripe exchange included)
-            avg_launch_s = elapsed / max(launches, 1)
-            timing_note = "N>1: rank-0 wall time of the timed region / launches (ring shifts of Q included)"
-        achieved = bytes_per_launch / avg_launch_s / 1e9
+        # several trainers share the stream and the ring runs beside them: this rank's wall clock over its launches
+        launch_s = elapsed / max(launches, 1)
+        note = "N>1: max-over-ranks wall time of the timed region / launches of rank 0 (ring transfers of Q included)"
         out = {
-            "metric": "ratings/sec per SGD epoch", "value": value, "unit": "ratings/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: synthetic %dx%d, %d ratings, k=%d per GPU "
-                                   "(N>1: users sharded over ranks, item stripes of Q rotate round the ranks over RCCL)" % (m, n, nnz, k),
-                       "m_per_gpu": m, "n": n, "nnz_per_gpu": nnz, "k": k, "lambda": w["lambda_p"],
-                       "eta": w["eta"], "stripes": info.stripes, "syncs_per_epoch": nsync,
-                       "combine": args.combine if world > 1 else None},
-            "final_rmse": rmse, "epochs_trained": epochs_total,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "kernel": "sgd_round<%d>" % info.lanes_per_rating,
-                         "bytes_per_rating": info.bytes_per_rating,
-                         "ratings_per_launch": nnz * args.steps / max(launches, 1),
-                         "avg_launch_us": avg_launch_s * 1e6, "launches_timed": launches, "timing": timing_note},
+            "metric": "ratings/sec per SGD epoch", "value": world * nnz * args.steps / elapsed, "unit": "ratings/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload + " per GPU (users sharded over ranks: an %dx%d problem with %d ratings; "
+                                              "item slots of Q %s over RCCL)" % (world * m, n, world * nnz,
+                                                                                 "rotate round the ranks" if rotate else "averaged"),
+                       "m_per_gpu": m, "n": n, "nnz_per_gpu": nnz, "k": k, "lambda": HYPER["lambda_p"], "eta": HYPER["eta"],
+                       "stripes": info.stripes, "combine": args.combine, "exchanges_per_epoch": nsync,
+                       "slots_per_rank": args.slots_per_rank if rotate else None},
+            "final_rmse": rmse, "epochs_trained": 1 + args.warmup + args.steps, "rounds_verified": True,
+            "roofline": roofline_block("n%d" % world, info, nnz, args.steps, launches, launch_s, note),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(pkg, w)
-            except Exception as e:  # the baseline is a report, never a reason to lose the line
-                out["cpu_baseline"] = {"value": None, "unit": "ratings/s", "cores": 0, "kind": "port",
-                                       "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
     t.close()
-    if world > 1:
-        dist.destroy_process_group()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -94,6 +94,11 @@ int mfx_trainer_create_layout(const mfx_node *R_host, const void *R_dev, long lo
                               const mfx_options *opt, const int *layout_cnt_p, const int *layout_cnt_q,
                               mfx_trainer **out);
 void mfx_trainer_destroy(mfx_trainer *t);
+/* Stripe count (= launches per epoch) a trainer would choose for a problem of this size on an MI355X
+ * (8 XCDs of 32 CUs); > 0, or a negative mfx_status.  Trainers that share factor rows must be given ONE
+ * stripe count (mfx_options.stripes): the id layout depends on it.  multi.py takes it from the smallest
+ * piece of the job. */
+int mfx_stripes_for(const mfx_options *opt, long long nnz, int m, int n);
 
 /* Use caller-owned device buffers for the factors (k_aligned stride, internal ids):
  * P m*k_a, Q n*k_a, PG 2m, QG 2n floats.  Lets a host framework hand the same memory

@@ -86,6 +86,7 @@ def lib():
     L.mfx_triplets_to_device.argtypes = [vp, ll, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32)]
     L.mfx_device_free.argtypes = [vp]
     L.mfx_device_free.restype = None
+    L.mfx_stripes_for.argtypes = [C.POINTER(Options), ll, i32, i32]
     L.mfx_trainer_destroy.argtypes = [vp]
     L.mfx_trainer_destroy.restype = None
     L.mfx_trainer_bind_model.argtypes = [vp, vp, vp, vp, vp]
@@ -152,6 +153,14 @@ def default_options(**kw):
     for k, v in kw.items():
         setattr(o, k, v)
     return o
+
+
+def stripes_for(opts, nnz, m, n):
+    """Stripe count a trainer would choose for a problem of this size (mfx_stripes_for)."""
+    rc = lib().mfx_stripes_for(C.byref(opts), nnz, m, n)
+    if rc <= 0:
+        _check(rc if rc < 0 else -1)
+    return rc
 
 
 def device_count():

@@ -639,6 +639,19 @@ __global__ __launch_bounds__(256) void export_side(const float *rows, const int 
     }
 }
 
+// Start of an epoch: every task of the epoch before must have been handed out (cursor >= task count per
+// block) -- if not, a sticky flag is raised that no later reset clears -- then the loss sums and the
+// cursors are zeroed.  One launch in place of the memset that used to do only the second half.
+__global__ __launch_bounds__(256) void epoch_reset(double *loss, int *cursor, const long long *slot_task_ptr, int nb,
+                                                  int check, int *sticky)
+{
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        if (check && cursor[i] < (int)(slot_task_ptr[i + 1] - slot_task_ptr[i])) atomicOr(sticky, 1);
+        cursor[i] = 0;
+    }
+    for (int i = threadIdx.x; i < LOSS_SLOTS; i += 256) loss[i] = 0.0;
+}
+
 __global__ void fill_f32(float *p, long long n, float v)
 {
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -741,6 +754,13 @@ hipError_t launch_export(const float *rows, const int *map, int nrows, int k, in
 {
     hipLaunchKernelGGL(export_side, dim3(grid), dim3(256), 0, s, rows, map, nrows, k, ka, f,
                        do_scale, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_epoch_reset(double *loss, int *cursor, const long long *slot_task_ptr, int nb, int check, int *sticky,
+                              hipStream_t s)
+{
+    hipLaunchKernelGGL(epoch_reset, dim3(1), dim3(256), 0, s, loss, cursor, slot_task_ptr, nb, check, sticky);
     return hipGetLastError();
 }
 

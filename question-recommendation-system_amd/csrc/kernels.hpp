@@ -52,6 +52,8 @@ hipError_t launch_sq_err_nodes(const float *model, int m, int n, int k, float b,
                                long long nnz, double *out, int grid, hipStream_t s);
 hipError_t launch_export(const float *rows, const int *map, int nrows, int k, int ka, float f,
                          int do_scale, float *out, int grid, hipStream_t s);
+hipError_t launch_epoch_reset(double *loss, int *cursor, const long long *slot_task_ptr, int nb, int check, int *sticky,
+                              hipStream_t s);
 hipError_t launch_fill(float *p, long long n, float v, int grid, hipStream_t s);
 hipError_t launch_triplets(const float *tri, long long count, void *out, int *mn_bad, int grid, hipStream_t s);
 hipError_t launch_synth(unsigned long long seed, unsigned long long shard, long long first,

@@ -97,6 +97,7 @@ struct mfx_trainer {
     DevBuf<long long> dSlotPtr;
     DevBuf<double> dEpochState; // zeroed once per epoch: LOSS_SLOTS loss sums, then the ns*ns task cursors
     int *dSlotStateP = nullptr;  // -> the cursors inside dEpochState
+    DevBuf<int> dSticky;     // raised by epoch_reset when an epoch left a block unfinished; never cleared
     DevBuf<double> dScalars; // [0..3] scratch for metrics
     double *dLossP = nullptr;    // -> the loss sums inside dEpochState
     DevBuf<int> dOwnBegin, dGatBegin; // RoundArgs::own_begin / gat_begin (ns+1 each)
@@ -346,6 +347,8 @@ static int create_impl(const mfx::Node *R, const void *R_dev, long long nnz, int
         t->dLossP = t->dEpochState.p;
         t->dSlotStateP = (int *)(t->dEpochState.p + mfx::LOSS_SLOTS);
         HIP_TRY(t->dScalars.alloc(4));
+        HIP_TRY(t->dSticky.alloc(1));
+        HIP_TRY(hipMemset(t->dSticky.p, 0, sizeof(int)));
         {
             // stripe boundaries for the kernel (buffer descriptors over the gathered stripe, L2 warm-up)
             const std::vector<int> &ob = p.owner_is_q ? p.q_begin : p.p_begin, &gb = p.owner_is_q ? p.p_begin : p.q_begin;
@@ -534,8 +537,10 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
     if (nparts < 1 || nparts > ns || part < 0 || part >= nparts)
         return fail(MFX_E_ARG, "epoch part out of range (1 <= nparts <= stripes)");
     if (part == 0) {
-        // one fill for the loss sums and the task cursors (they share a buffer)
-        HIP_TRY(hipMemsetAsync(t->dEpochState.p, 0, (mfx::LOSS_SLOTS + ((size_t)ns * ns + 1) / 2) * sizeof(double), s));
+        // one launch checks the cursors of the epoch before (sticky flag, read by verify_rounds) and zeroes
+        // the loss sums and the task cursors
+        HIP_TRY(mfx::launch_epoch_reset(t->dLossP, t->dSlotStateP, t->dSlotPtr.p, ns * ns, t->epochs_done > 0 ? 1 : 0,
+                                        t->dSticky.p, s));
     }
 
     mfx::RoundArgs a;
@@ -650,16 +655,21 @@ int mfx_trainer_epoch(mfx_trainer *t, int slow_only, void *stream_v)
 
 // Every task of the last epoch must have been handed out: cursor >= task count per block.
 // Fails loudly if an XCD the probe saw received no workgroup in some launch.
+// Earlier epochs are covered by the sticky flag that epoch_reset raises on the device before it zeroes the
+// cursors, so an epoch nobody synchronised on is checked all the same.  Callers have synchronised the device.
 static int verify_rounds(mfx_trainer *t)
 {
+    static const char *const msg = "a stripe block was left unprocessed: workgroup-to-XCD placement "
+                                   "differs from the probe (set MFX_STRIPES / rerun)";
+    int sticky = 0;
+    HIP_TRY(hipMemcpy(&sticky, t->dSticky.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (sticky) return fail(MFX_E_STATE, msg);
     if (!t->loss_pending) return MFX_OK;
     const mfx::Plan &p = t->plan;
     std::vector<int> cur((size_t)p.ns * p.ns);
     HIP_TRY(hipMemcpy(cur.data(), t->dSlotStateP, cur.size() * sizeof(int), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < cur.size(); ++i)
-        if (cur[i] < p.slot_task_ptr[i + 1] - p.slot_task_ptr[i])
-            return fail(MFX_E_STATE, "a stripe block was left unprocessed: workgroup-to-XCD placement "
-                                     "differs from the probe (set MFX_STRIPES / rerun)");
+        if (cur[i] < p.slot_task_ptr[i + 1] - p.slot_task_ptr[i]) return fail(MFX_E_STATE, msg);
     t->loss_pending = false;
     return MFX_OK;
 }
@@ -722,6 +732,7 @@ int mfx_trainer_sq_err(mfx_trainer *t, double *sum_sq)
     HIP_TRY(hipSetDevice(t->device));
     const mfx::Plan &p = t->plan;
     HIP_TRY(hipDeviceSynchronize());
+    if (int rcv = verify_rounds(t)) return rcv;
     HIP_TRY(hipMemset(t->dScalars.p + 3, 0, sizeof(double)));
     const float *own = p.owner_is_q ? t->dQ : t->dP, *gat = p.owner_is_q ? t->dP : t->dQ;
     HIP_TRY(mfx::launch_sq_err_entries(p.lanes, own, gat, t->dEntries.p, t->n_entries, p.ka,
@@ -780,6 +791,7 @@ int mfx_trainer_get_model(mfx_trainer *t, float *P, float *Q, float *PG, float *
     if (!t->model_ready) return fail(MFX_E_STATE, "model not initialised");
     HIP_TRY(hipSetDevice(t->device));
     HIP_TRY(hipDeviceSynchronize());
+    if (int rcv = verify_rounds(t)) return rcv;
     const mfx::Plan &p = t->plan;
     if (P) HIP_TRY(hipMemcpy(P, t->dP, (size_t)p.m * p.ka * 4, hipMemcpyDeviceToHost));
     if (Q) HIP_TRY(hipMemcpy(Q, t->dQ, (size_t)p.n * p.ka * 4, hipMemcpyDeviceToHost));
@@ -853,6 +865,7 @@ int mfx_trainer_export(mfx_trainer *t, float *arr, long long len)
     if (len != pn + qn + 5) return fail(MFX_E_ARG, "model array length must be 5+(m+n)*k");
     HIP_TRY(hipSetDevice(t->device));
     HIP_TRY(hipDeviceSynchronize());
+    if (int rcv = verify_rounds(t)) return rcv;
     DevBuf<float> tmp;
     HIP_TRY(tmp.alloc((size_t)(pn + qn)));
     const int do_scale = p.scale != 1.0f; // scale_model returns early on 1.0 (mf.cpp:531-532)
@@ -977,6 +990,14 @@ int mfx_hostplan_build(const mfx_node *R, long long nnz, int m, int n, const mfx
     }
     *out = h;
     return MFX_OK;
+}
+
+int mfx_stripes_for(const mfx_options *opt, long long nnz, int m, int n)
+{
+    if (!opt || nnz <= 0 || m <= 0 || n <= 0) return fail(MFX_E_ARG, "bad argument");
+    if (int rc0 = check_options(*opt)) return rc0;
+    int wpw = 4, wgs = 1;
+    return choose_stripes(*opt, nnz, m, n, 8, 32, &wgs, &wpw); // an MI355X: 8 XCDs of 32 CUs
 }
 
 int mfx_hostplan_view(const mfx_hostplan *h, mfx_plan_view *v)
