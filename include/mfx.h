@@ -175,6 +175,7 @@ typedef struct mfx_plan_view {
     const void *tasks;              /* {uint64 entry_off, uint32 nsteps, uint32 pad}            */
     const long long *slot_task_ptr; /* stripes*stripes+1, ordered (round, slot)                */
     const int *p_begin, *q_begin;   /* stripes+1 internal-id boundaries of the user / item stripes */
+    long long n_hot_slots;          /* owner rows that are cut into chains somewhere (combine slots of the kernel) */
 } mfx_plan_view;
 int mfx_hostplan_build(const mfx_node *R_host, long long nnz, int m, int n,
                        const mfx_options *opt, mfx_hostplan **out);

@@ -181,8 +181,17 @@ static int cmp_by_q(const void *a, const void *b)
 /* grid_problem, mf.cpp:793-858.  R is permuted in place into nr_bins^2
  * contiguous blocks, each sorted by (u,v) when m > n, else by (v,u).  With
  * unique (u,v) pairs the result does not depend on the sort algorithm. */
+static void grid_problem_sorted(orc_node *R, long long nnz, int m, int n, int nr_bins, long long *ptrs,
+                                int *omega_p, int *omega_q, int by_p);
+
 void orc_grid_problem(orc_node *R, long long nnz, int m, int n, int nr_bins,
                       long long *ptrs /* nr_bins^2+1 */, int *omega_p, int *omega_q)
+{
+    grid_problem_sorted(R, nnz, m, n, nr_bins, ptrs, omega_p, omega_q, m > n);
+}
+
+static void grid_problem_sorted(orc_node *R, long long nnz, int m, int n, int nr_bins, long long *ptrs,
+                                int *omega_p, int *omega_q, int by_p)
 {
     int nb = nr_bins * nr_bins;
     int seg_p = (int)ceil((double)m / nr_bins);
@@ -222,7 +231,9 @@ void orc_grid_problem(orc_node *R, long long nnz, int m, int n, int nr_bins,
     }
     for (b = 0; b < nb; b++)
         qsort(R + ptrs[b], (size_t)(ptrs[b + 1] - ptrs[b]), sizeof(orc_node),
-              m > n ? cmp_by_p : cmp_by_q);
+              by_p ? cmp_by_p : cmp_by_q);
+    (void)m;
+    (void)n;
     free(counts);
     free(pivots);
 }
@@ -412,8 +423,26 @@ orc_param orc_default_param(void)
 }
 
 /* fpsg + fpsg_core + mf_train_with_validation for P_L2_MFR, one worker. */
+static int train_core(const orc_node *R_in, long long nnz, int m, int n, const orc_param *prm,
+                      orc_model *out, double *tr_rmse, double *obj, const orc_order *ord);
+
 int orc_train(const orc_node *R_in, long long nnz, int m, int n, const orc_param *prm,
               orc_model *out, double *tr_rmse, double *obj)
+{
+    return train_core(R_in, nnz, m, n, prm, out, tr_rmse, obj, NULL);
+}
+
+/* ORDER STUDY (not the reference's behaviour): the same arithmetic, the same pre-processing, but the ratings
+ * are visited in another order -- used to find out how much of a difference in final RMSE is a matter of
+ * order alone.  ord == NULL in orc_train: the reference's order. */
+int orc_train_order(const orc_node *R_in, long long nnz, int m, int n, const orc_param *prm,
+                    orc_model *out, double *tr_rmse, double *obj, const orc_order *ord)
+{
+    return train_core(R_in, nnz, m, n, prm, out, tr_rmse, obj, ord);
+}
+
+static int train_core(const orc_node *R_in, long long nnz, int m, int n, const orc_param *prm,
+                      orc_model *out, double *tr_rmse, double *obj, const orc_order *ord)
 {
     int nb, ka, k = prm->k, iter, b;
     orc_node *R;
@@ -470,7 +499,8 @@ int orc_train(const orc_node *R_in, long long nnz, int m, int n, const orc_param
             R[i].r *= inv_scale;
 
     ptrs = (long long *)malloc((size_t)(nb + 1) * sizeof(long long));
-    orc_grid_problem(R, nnz, m, n, prm->nr_bins, ptrs, omega_p, omega_q);
+    grid_problem_sorted(R, nnz, m, n, prm->nr_bins, ptrs, omega_p, omega_q,
+                        ord && ord->sort_side ? ord->sort_side == 2 : m > n);
 
     P = (float *)aligned_alloc(32, sizeof(float) * (size_t)m * (size_t)ka);
     Q = (float *)aligned_alloc(32, sizeof(float) * (size_t)n * (size_t)ka);
@@ -497,7 +527,30 @@ int orc_train(const orc_node *R_in, long long nnz, int m, int n, const orc_param
             hent e = hpop(heap, &hn); /* get_job: nothing else is busy */
             double loss = 0;
             long long t;
+            if (ord && ord->block_order) { /* order study: cyclic rounds of stripe-disjoint blocks */
+                int bins = prm->nr_bins, r = job / bins, s = job % bins;
+                if (ord->block_order == 2)
+                    r = (r + iter) % bins; /* rotate the first round per epoch */
+                e.id = s * bins + (s + r) % bins;
+            }
             counts[e.id]++;
+            if (ord && ord->lists > 1) { /* order study: the block's sorted ratings dealt over `lists` lists that advance together */
+                long long beg = ptrs[e.id], len = ptrs[e.id + 1] - beg, L = ord->lists;
+                long long chunk = (len + L - 1) / L, step, l;
+                for (step = 0; step < chunk; step++)
+                    for (l = 0; l < L; l++) {
+                        long long idx = l * chunk + step;
+                        orc_node *N;
+                        float err;
+                        if (idx >= len || step >= chunk)
+                            continue;
+                        N = &R[beg + idx];
+                        err = orc_sgd_one(P + (long long)N->u * ka, Q + (long long)N->v * ka, PG + 2LL * N->u,
+                                          QG + 2LL * N->v, N->r, ka, lambda_p, lambda_q, prm->eta, slow_only,
+                                          prm->rsqrt_mode, prm->rk_mode);
+                        loss += (double)(err * err);
+                    }
+            } else
             for (t = ptrs[e.id]; t < ptrs[e.id + 1]; t++) {
                 orc_node *N = &R[t];
                 float err = orc_sgd_one(P + (long long)N->u * ka, Q + (long long)N->v * ka,

@@ -50,6 +50,19 @@ float orc_sgd_one(float *p, float *q, float *pG, float *qG, float r, int ka,
 orc_param orc_default_param(void);
 int orc_train(const orc_node *R, long long nnz, int m, int n, const orc_param *prm,
               orc_model *out, double *tr_rmse, double *obj);
+/* order study (mf_oracle.c: orc_train_order): 0 everywhere = the reference's order */
+typedef struct {
+    int block_order; /* 0 the reference's scheduler; 1 cyclic rounds (s, (s+r) mod bins); 2 the same, first round rotated per epoch */
+    int sort_side;   /* 0 as the reference (by user when m > n); 1 by item, then user; 2 by user, then item */
+    int lists;       /* > 1: a block's ratings are dealt over this many lists that advance in lock step */
+} orc_order;
+int orc_train_order(const orc_node *R, long long nnz, int m, int n, const orc_param *prm,
+                    orc_model *out, double *tr_rmse, double *obj, const orc_order *ord);
+/* plan_order.c: orc_sgd_one over the GPU plan's own entry stream (see the header of that file) */
+int orc_plan_order_train(const void *entries, const void *tasks, const long long *slot_task_ptr, int ns, int G,
+                         int ka, int owner_is_q, float *P, float *Q, float *PG, float *QG, long long n_hot_slots,
+                         float lambda_p, float lambda_q, float eta, int epochs, int first_epoch, int chain_mode,
+                         int rsqrt_mode, int rk_mode, double *epoch_loss);
 void orc_free_model(orc_model *mdl);
 
 float orc_predict(const orc_model *mdl, int u, int v);

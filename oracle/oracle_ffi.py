@@ -28,6 +28,10 @@ class Model(C.Structure):
                 ("b", C.c_float), ("P", C.POINTER(C.c_float)), ("Q", C.POINTER(C.c_float))]
 
 
+class Order(C.Structure):
+    _fields_ = [("block_order", C.c_int), ("sort_side", C.c_int), ("lists", C.c_int)]
+
+
 class GlibcRand(C.Structure):
     _fields_ = [("r", C.c_int32 * 31), ("f", C.c_int), ("b", C.c_int)]
 
@@ -45,6 +49,9 @@ def lib():
         L = C.CDLL(path)
         vp, ll, i32, f32 = C.c_void_p, C.c_longlong, C.c_int, C.c_float
         L.orc_train.argtypes = [vp, ll, i32, i32, C.POINTER(Param), C.POINTER(Model), vp, vp]
+        L.orc_train_order.argtypes = [vp, ll, i32, i32, C.POINTER(Param), C.POINTER(Model), vp, vp, C.POINTER(Order)]
+        L.orc_plan_order_train.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, ll, f32, f32, f32, i32, i32,
+                                           i32, i32, i32, vp]
         L.orc_rmse.restype = C.c_double
         L.orc_rmse.argtypes = [vp, ll, C.POINTER(Model)]
         L.orc_predict.restype = f32
@@ -107,7 +114,7 @@ def k_aligned(k):
 
 
 def train(R, m, n, k=8, iters=20, bins=20, lambda_p=0.1, lambda_q=0.1, eta=0.1,
-          rsqrt_mode=RSQRT_SSE, rk_mode=RK_AS_BUILT, progress=False):
+          rsqrt_mode=RSQRT_SSE, rk_mode=RK_AS_BUILT, progress=False, order=None):
     """One-worker restatement of mf_train.  Returns the facade array [fun,m,n,k,b,P,Q]
     (and the per-iteration (tr_rmse, obj) table when progress=True)."""
     R = np.ascontiguousarray(R, dtype=NODE)
@@ -115,8 +122,13 @@ def train(R, m, n, k=8, iters=20, bins=20, lambda_p=0.1, lambda_q=0.1, eta=0.1,
     mdl = Model()
     tr = np.zeros(iters)
     ob = np.zeros(iters)
-    rc = lib().orc_train(R.ctypes.data, len(R), m, n, C.byref(prm), C.byref(mdl),
-                         tr.ctypes.data if progress else None, ob.ctypes.data if progress else None)
+    if order is not None:  # order study: (block_order, sort_side, lists), see mf_oracle.h
+        od = Order(*order)
+        rc = lib().orc_train_order(R.ctypes.data, len(R), m, n, C.byref(prm), C.byref(mdl),
+                                   tr.ctypes.data if progress else None, ob.ctypes.data if progress else None, C.byref(od))
+    else:
+        rc = lib().orc_train(R.ctypes.data, len(R), m, n, C.byref(prm), C.byref(mdl),
+                             tr.ctypes.data if progress else None, ob.ctypes.data if progress else None)
     if rc != 0:
         raise RuntimeError("orc_train failed: %d" % rc)
     P = np.ctypeslib.as_array(mdl.P, (m * k,)).copy()
@@ -124,6 +136,38 @@ def train(R, m, n, k=8, iters=20, bins=20, lambda_p=0.1, lambda_q=0.1, eta=0.1,
     arr = np.concatenate([np.array([mdl.fun, mdl.m, mdl.n, mdl.k, mdl.b], dtype=np.float32), P, Q])
     lib().orc_free_model(C.byref(mdl))
     return (arr, tr, ob) if progress else arr
+
+
+CHAIN_LAST_WINS, CHAIN_FOLD, CHAIN_SHARED = 0, 1, 2
+
+
+def plan_order_train(hp, epochs, lambda_p=0.1, lambda_q=0.1, eta=0.1, chain_mode=CHAIN_FOLD,
+                     rsqrt_mode=RSQRT_EXACT, rk_mode=RK_AS_BUILT):
+    """The oracle's update (orc_sgd_one) applied in the order of a GPU plan (`hp`: the package's HostPlan).
+    Returns (facade array [fun,m,n,k,b,P,Q] in original ids, per-epoch online tr_rmse) -- what the GPU trainer
+    would produce if nothing but the ORDER of the ratings distinguished it from the reference (plan_order.c)."""
+    v = hp.view
+    P, Q = hp.init_factors()
+    PG = np.ones((v.m, 2), dtype=np.float32)
+    QG = np.ones((v.n, 2), dtype=np.float32)
+    loss = np.zeros(epochs)
+    scale = np.float32(v.scale)
+    ent, tsk, sp = np.ascontiguousarray(hp.entries), np.ascontiguousarray(hp.tasks), np.ascontiguousarray(hp.slot_task_ptr)
+    rc = lib().orc_plan_order_train(ent.ctypes.data, tsk.ctypes.data, sp.ctypes.data, v.stripes, v.ratings_per_wave,
+                                    v.k_aligned, v.owner_is_q, P.ctypes.data, Q.ctypes.data, PG.ctypes.data, QG.ctypes.data,
+                                    v.n_hot_slots, np.float32(lambda_p) / scale, np.float32(lambda_q) / scale, eta, epochs, 0,
+                                    chain_mode, rsqrt_mode, rk_mode, loss.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("orc_plan_order_train failed: %d" % rc)
+    # export like the trainer: scale_model, shrink_model, shuffle_model (reference mf/mf.cpp:529-553, 1057-1074, 1027-1055)
+    f = np.float32(np.sqrt(scale)) if scale != 1.0 else np.float32(1.0)
+    Po = P[hp.p_map][:, :v.k] * f
+    Qo = Q[hp.q_map][:, :v.k] * f
+    b = np.float32(v.avg) / scale
+    if scale != 1.0:
+        b = b * scale
+    arr = np.concatenate([np.array([0, v.m, v.n, v.k, b], dtype=np.float32), Po.ravel().astype(np.float32), Qo.ravel().astype(np.float32)])
+    return arr, np.sqrt(loss / v.nnz) * float(scale)
 
 
 def _model_of(arr):

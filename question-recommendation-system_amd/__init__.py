@@ -64,7 +64,7 @@ class PlanView(C.Structure):
                 ("inv_scale", C.c_float), ("p_map", C.c_void_p), ("q_map", C.c_void_p),
                 ("omega_p", C.c_void_p), ("omega_q", C.c_void_p), ("entries", C.c_void_p),
                 ("tasks", C.c_void_p), ("slot_task_ptr", C.c_void_p),
-                ("p_begin", C.c_void_p), ("q_begin", C.c_void_p)]
+                ("p_begin", C.c_void_p), ("q_begin", C.c_void_p), ("n_hot_slots", C.c_longlong)]
 
 
 _lib = None

@@ -249,6 +249,9 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                 int nsteps_n = 0;
 
                 unsigned cur = NONE;  // owner row held in registers
+                int hot_n = 0;        // > 0: the visit in progress is one of hot_n chains of a hot row (this launch)
+                unsigned hot_h = 0;   //      with combine slot (bits 0..19) and this chain's length (bits 20..31)
+                float hot_e0 = 0.0f;  //      list's squared-error sum when the chain began
                 f4 o = zero4;
                 float og0 = 1.0f, og1 = 1.0f;
                 unsigned pf = NONE;   // owner row in flight for the next visit
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                 EntryD r0 = nb0, r1 = nb1; // block 0 was fetched while the task before ran
                 park_block(0, r0, r1);
                 EntryD e = entry_of(0);
-                if (e.gat >= 0) { // every list starts with a visit: fetch its owner row now
+                if (e.gat != -1) { // every list starts with a visit (or the header of a hot chain): fetch its owner row now
                     pf = e.own & IDMASK;
                     if (lane_ok) on = ld_row(a.own_rows + (size_t)pf * ka + d0);
                     ogn = ld_acc(a.own_acc + (size_t)pf * 2);
@@ -312,6 +315,37 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                 c_task += tk1 - tk0;
                 n_tasks++;
 #endif
+                // ---- hot chains ----
+                // An owner row with more ratings in the block than one list should hold is cut into chains
+                // (plan.cpp), each run on its own register copy of the row -- possibly at the same time in
+                // other waves.  A chain does not write the row: it adds its end state (row, the two accumulator
+                // slots, its squared errors, its length, 1) to the row's combine slot with fire-and-forget float
+                // atomics; fold_hot_rows, launched behind every round, folds the sums into the row (see there).
+                // (A slot is HOT_SUB partial sums: hundreds of chains of one row adding to the same words would
+                //  queue at one memory channel, ~12 ns per wave instruction -- 47 us for the head row of configs[1].)
+                auto close_visit = [&]() {
+                    if (hot_n == 0) {
+                        if (lane_ok) *(f4 *)(a.own_rows + (size_t)cur * ka + d0) = o;
+                        if (lig == 0) *(f2 *)(a.own_acc + (size_t)cur * 2) = f2{og0, og1};
+                        return;
+                    }
+                    float *const slot = a.hot_acc + ((size_t)(hot_h & 0xFFFFFu) * HOT_SUB +
+                                                     (size_t)(((blockIdx.x * 4 + (threadIdx.x >> 6)) * G + grp) & (HOT_SUB - 1))) *
+                                                        (size_t)(ka + HOT_EXTRA);
+                    if (lane_ok) {
+                        unsafeAtomicAdd(slot + d0 + 0, o.x);
+                        unsafeAtomicAdd(slot + d0 + 1, o.y);
+                        unsafeAtomicAdd(slot + d0 + 2, o.z);
+                        unsafeAtomicAdd(slot + d0 + 3, o.w);
+                    }
+                    if (lig == 0) {
+                        unsafeAtomicAdd(slot + ka, og0);
+                        unsafeAtomicAdd(slot + ka + 1, og1);
+                        unsafeAtomicAdd(slot + ka + 2, tsum - hot_e0);        // squared errors of this chain
+                        unsafeAtomicAdd(slot + ka + 3, (float)(hot_h >> 20)); // its ratings
+                        unsafeAtomicAdd(slot + ka + 4, 1.0f);                 // one more chain
+                    }
+                };
                 for (int step = 0; step < nsteps; ++step) {
                     STAMP(ts0);
                     // (read under the wait below; stale past the end of the list, see nact; the
@@ -320,12 +354,13 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     const bool act = e.gat >= 0;
                     const unsigned id = e.own & IDMASK;
                     const float rating = e.r;
-                    const bool newvisit = act && (e.own >> 31) && id != cur;
+                    const bool hdr = e.gat < -1; // header entry of a hot chain: always starts a visit of its own
+                    const bool newvisit = (act || hdr) && (e.own >> 31) && (id != cur || hdr);
                     if (newvisit) { // switch the owner row: write the old one back, take the prefetched one
-                        if (cur != NONE) {
-                            if (lane_ok) *(f4 *)(a.own_rows + (size_t)cur * ka + d0) = o;
-                            if (lig == 0) *(f2 *)(a.own_acc + (size_t)cur * 2) = f2{og0, og1};
-                        }
+                        if (cur != NONE) close_visit();
+                        hot_n = hdr ? ((-e.gat - 1) & 0x7FFF) | ((-e.gat - 1) >> 15 << 16) : 0; // chains | index << 16
+                        hot_h = __builtin_bit_cast(unsigned, rating);
+                        hot_e0 = tsum;
                         if (pf != id) { // not prefetched (cannot happen for lists built by plan.cpp)
                             if (lane_ok) on = ld_row(a.own_rows + (size_t)id * ka + d0);
                             ogn = ld_acc(a.own_acc + (size_t)id * 2);
@@ -394,7 +429,8 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     gacc = nact ? (unsigned)(enext.gat - gfirst) * 8u : BUF_OOB;
                     const unsigned id1 = enext.own & IDMASK;
                     auto owner_prefetch = [&]() {
-                        if (nact && (enext.own >> 31) && id1 != cur) { // a visit starts at the next step
+                        const bool nhdr = enext.gat < -1 && step + 1 < nsteps;
+                        if ((nact || nhdr) && (enext.own >> 31) && (id1 != cur || nhdr)) { // a visit starts at the next step
                             pf = id1;
                             if (lane_ok) on = ld_row(a.own_rows + (size_t)id1 * ka + d0);
                             ogn = ld_acc(a.own_acc + (size_t)id1 * 2);
@@ -442,10 +478,7 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     n_steps++;
 #endif
                 }
-                if (cur != NONE) {
-                    if (lane_ok) *(f4 *)(a.own_rows + (size_t)cur * ka + d0) = o;
-                    if (lig == 0) *(f2 *)(a.own_acc + (size_t)cur * 2) = f2{og0, og1};
-                }
+                if (cur != NONE) close_visit();
                 if (lig == 0) lsum += (double)tsum;
                 // a task that ended before the hand-over was through does the rest now
                 STAMP(tk0);
@@ -493,6 +526,67 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
         const double s = wg_loss[0] + wg_loss[1] + wg_loss[2] + wg_loss[3];
         if (s != 0.0) atomicAdd(a.loss + (blockIdx.x % LOSS_SLOTS), s);
     }
+}
+
+// Fold the chains of the hot rows into their rows (launched behind every round; one wave per combine slot).
+// Round 1 let the last writer win: a row cut into n chains kept 1/n of its updates and of its accumulator growth,
+// so its step size stayed too large and the whole run fitted the training set 2-3 % faster than the reference.
+// Now no update and no accumulator increment is lost.  The fold is a 1-D model of what the reference does
+// sequentially (DESIGN.md "Hot rows"): all chains start from the row p0 of before the launch.  With
+// S = sum over the ratings of (step size x curvature), a sequential pass moves the row by (1 - exp(-S_seq)) of the
+// way to the block's optimum, a chain by (1 - exp(-S_chain)); the summed change of the n chains is therefore scaled
+// by (1 - exp(-S_seq)) / (n (1 - exp(-S_chain))): exactly 1 for one chain, the plain sum (first-order equivalence)
+// while S is small, never beyond the optimum for a row that holds a large part of the block.  Step sizes come from
+// the Adagrad accumulators (sequentially G runs from G0 to G0 + A, in a chain to G0 + A/n: mean step
+// 2 eta / (sqrt(G_end) + sqrt(G0))), the curvature |q|^2 from the accumulator growth over the squared errors
+// (A = rk * sum e^2 |q|^2): nothing extra is computed per rating.
+__global__ __launch_bounds__(256) void fold_hot_rows(float *rows, float *acc, float *hot_acc, const int *hot_row,
+                                                     int n_slots, int ka, float eta, float rk1, int slow_only, int fold_mode)
+{
+    const int lane = threadIdx.x & 63;
+    const int slot_i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot_i >= n_slots) return;
+    const int stride = ka + HOT_EXTRA;
+    float *const s0 = hot_acc + (size_t)slot_i * HOT_SUB * stride;
+    float ex[HOT_EXTRA] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f}; // sum G0-slot, sum G1-slot, squared errors, ratings, chains
+    if (lane < HOT_EXTRA)
+        for (int sub = 0; sub < HOT_SUB; ++sub) ex[0] += s0[(size_t)sub * stride + ka + lane];
+    const float v = ex[0];
+#pragma unroll
+    for (int j = 0; j < HOT_EXTRA; ++j) ex[j] = __shfl(v, j);
+    const float n = ex[4];
+    if (!(n > 0.0f)) return; // the row had no chain in this round
+    const int row = hot_row[slot_i];
+    const float g00 = acc[(size_t)row * 2], g01 = acc[(size_t)row * 2 + 1];
+    const float A0 = fmaxf(ex[0] - n * g00, 0.0f), A1 = fmaxf(ex[1] - n * g01, 0.0f), E = ex[2], N = ex[3];
+    const float rn = 1.0f / n;
+    const float r00 = __builtin_sqrtf(g00), r01 = __builtin_sqrtf(g01);
+    // mean step sizes (/ 2 eta) of a sequential pass and of a chain, per accumulator slot
+    const float ts0 = 1.0f / (__builtin_sqrtf(g00 + A0) + r00), ts1 = 1.0f / (__builtin_sqrtf(g01 + A1) + r01);
+    const float tc0 = 1.0f / (__builtin_sqrtf(g00 + A0 * rn) + r00), tc1 = 1.0f / (__builtin_sqrtf(g01 + A1 * rn) + r01);
+    const float cq = E > 0.0f ? 2.0f * eta * N / E : 0.0f; // sum of |q|^2 over the ratings, per slot: N * A / (rk * E)
+    const float c0 = cq * A0 * 8.0f, c1 = cq * A1 / rk1;
+    const float Sseq = ts0 * c0 + ts1 * c1, Sch = (tc0 * c0 + tc1 * c1) * rn;
+    auto damp = [](float S) { return S > 1e-3f ? (1.0f - __expf(-S)) / S : 1.0f - 0.5f * S; };
+    // HOT_S_GAIN: while the chains hold the row still, the rows on the other side of the row's ratings all move against
+    // the same unmoved value, so the error shrinks faster than the row's own curvature says; the factor was calibrated
+    // on the order emulation (oracle/plan_order.c: final RMSE of the plan's order with chains vs without, three data
+    // sets within +-0.4 %; tests/tools/order_study.py)
+    const float phi = damp(HOT_S_GAIN * Sseq) / damp(HOT_S_GAIN * Sch); // (1-exp(-S)) / (n (1-exp(-S/n))) in the symmetric case
+    // fold_mode 0: the damped sum above; 1 (experiment): the row becomes the MEAN of the chains' end states
+    const float sc0 = fold_mode == 1 ? rn : phi * ts0 / tc0, sc1 = fold_mode == 1 ? rn : phi * ts1 / tc1;
+    for (int d = lane; d < (slow_only ? 8 : ka); d += 64) { // (epoch 0 moves the first eight factors only)
+        float sum = 0.0f;
+        for (int sub = 0; sub < HOT_SUB; ++sub) sum += s0[(size_t)sub * stride + d];
+        const float p0 = rows[(size_t)row * ka + d];
+        rows[(size_t)row * ka + d] = p0 + (d >= 8 ? sc1 : sc0) * (sum - n * p0);
+    }
+    if (lane == 0) {
+        acc[(size_t)row * 2] = g00 + A0;
+        acc[(size_t)row * 2 + 1] = g01 + A1;
+    }
+    // leave zeros for the next round
+    for (int i = lane; i < HOT_SUB * stride; i += 64) s0[i] = 0.0f;
 }
 
 // Which XCC ids does a grid land on?  One bit per id seen (run once per trainer).
@@ -701,6 +795,15 @@ hipError_t launch_sgd_round(int lanes, const RoundArgs &a, int grid, hipStream_t
     case 64: launch_round_t<64>(a, grid, s); break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_fold_hot(float *rows, float *acc, float *hot_acc, const int *hot_row, int n_slots, int ka, float eta,
+                           float rk1, int slow_only, int fold_mode, hipStream_t s)
+{
+    if (n_slots <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fold_hot_rows, dim3((n_slots + 3) / 4), dim3(256), 0, s, rows, acc, hot_acc, hot_row, n_slots, ka,
+                       eta, rk1, slow_only, fold_mode);
     return hipGetLastError();
 }
 

@@ -10,6 +10,9 @@ struct EntryD { uint32_t own; int32_t gat; float r; };
 struct TaskDescD { uint64_t off; uint32_t nsteps; uint32_t pad; };
 
 constexpr int LOSS_SLOTS = 256; // the epoch loss is kept as this many partial sums
+constexpr int HOT_SUB = 8;      // a hot row's combine slot is kept as this many partial sums of (ka + HOT_EXTRA) floats:
+constexpr float HOT_S_GAIN = 4.0f; // fold_hot_rows: gain on the contraction estimate (calibrated, see there)
+constexpr int HOT_EXTRA = 5;    // the row, then both accumulator slots, squared errors, ratings, chains
 
 // Arguments of one SGD round (= one launch = NS stripe-disjoint blocks).
 struct RoundArgs {
@@ -17,6 +20,7 @@ struct RoundArgs {
     float *gat_rows;  // factors of the gathered side (n_gat x ka)
     float *own_acc;   // Adagrad slots, 2 per row (reference PG/QG, mf.cpp:2835)
     float *gat_acc;
+    float *hot_acc;   // combine slots of the hot rows (HOT_SUB x (ka + HOT_EXTRA) floats each), zero between rounds
     const EntryD *entries;
     const TaskDescD *tasks;
     const long long *slot_task_ptr; // ns+1 task offsets of this round
@@ -40,6 +44,8 @@ struct RoundArgs {
 };
 
 hipError_t launch_sgd_round(int lanes, const RoundArgs &a, int grid, hipStream_t s);
+hipError_t launch_fold_hot(float *rows, float *acc, float *hot_acc, const int *hot_row, int n_slots, int ka, float eta,
+                           float rk1, int slow_only, int fold_mode, hipStream_t s);
 hipError_t launch_probe_xcc(unsigned *mask, int grid, hipStream_t s);
 hipError_t launch_sq_err_entries(int lanes, const float *own_rows, const float *gat_rows,
                                  const EntryD *entries, long long n_entries, int ka, double *out,

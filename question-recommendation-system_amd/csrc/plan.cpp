@@ -94,9 +94,11 @@ void pack_class(const std::vector<Visit> &visits, size_t vbeg, size_t vend, int 
                 BlockPack &out, long long force_ntasks = 0)
 {
     if (vbeg >= vend) return;
+    // load of a visit in steps: its ratings, plus the header entry of a hot chain
+    auto steps_of = [](const Visit &v) { return v.len + (v.nch ? 1u : 0u); };
     long long L = 0;
-    for (size_t i = vbeg; i < vend; ++i) L += visits[i].len;
-    target = std::max<long long>(target, visits[vbeg].len); // visits are sorted, longest first
+    for (size_t i = vbeg; i < vend; ++i) L += steps_of(visits[i]);
+    target = std::max<long long>(target, steps_of(visits[vbeg])); // visits are sorted, longest first
     long long ntasks = (L + (long long)G * target - 1) / ((long long)G * target);
     if (force_ntasks > 0) ntasks = force_ntasks;
     if (ntasks < 1) ntasks = 1;
@@ -110,7 +112,7 @@ void pack_class(const std::vector<Visit> &visits, size_t vbeg, size_t vend, int 
         LB top = heap.top();
         heap.pop();
         list_visits[top.second].push_back((uint32_t)vi);
-        load[top.second] = top.first + visits[vi].len;
+        load[top.second] = top.first + steps_of(visits[vi]);
         heap.push({load[top.second], top.second});
     }
     std::vector<uint32_t> order(NG);
@@ -131,6 +133,10 @@ void pack_class(const std::vector<Visit> &visits, size_t vbeg, size_t vend, int 
             uint32_t step = 0;
             for (uint32_t vi : list_visits[lst]) {
                 const Visit &v = visits[vi];
+                if (v.nch) { // hot chain: a header entry first
+                    out.headers.push_back({base + (uint64_t)step * G + g, v.own, v.nch, v.hot | (v.len << 20), v.idx});
+                    ++step;
+                }
                 out.places.push_back({v.start, base + (uint64_t)step * G + g, v.len, 0u});
                 step += v.len;
             }
@@ -143,14 +149,15 @@ void pack_class(const std::vector<Visit> &visits, size_t vbeg, size_t vend, int 
 } // namespace
 
 // Cut one (owner-stripe, gather-stripe) block, given as its visits, into wavefront tasks.
-void pack_visits(std::vector<Visit> &raw, int G, int target, int hot_len, BlockPack &out, int one_task_waves)
+void pack_visits(std::vector<Visit> &raw, int G, int target, int hot_len, BlockPack &out, int one_task_waves,
+                 const std::vector<int> *hot_slot_of_row)
 {
     if (raw.empty()) return;
     // A visit (all ratings of one owner row in this block) longer than hot_len is cut into
-    // chains that may run in different lane groups (each works on its own copy of the owner row
-    // and the last one to finish wins -- measured to cost less RMSE than exchanging the row
-    // through memory every few ratings, DESIGN.md "Hot rows").  No list is longer than the
-    // longest visit, so hot_len also bounds the longest task of the launch.
+    // chains that may run in different lane groups, each on its own register copy of the owner row;
+    // when the last chain of the launch ends, the chains' changes are folded into the row (kernels.hip,
+    // "hot chains"; DESIGN.md "Hot rows").  No list is longer than the longest visit, so hot_len also
+    // bounds the longest task of the launch.
     std::vector<Visit> visits;
     visits.reserve(raw.size());
     long long L = 0;
@@ -159,8 +166,13 @@ void pack_visits(std::vector<Visit> &raw, int G, int target, int hot_len, BlockP
         if ((long long)v.len > hot_len) {
             long long nch = ((long long)v.len + hot_len - 1) / hot_len;
             long long per = ((long long)v.len + nch - 1) / nch;
+            long long made = 0;
+            for (long long s = 0; s < v.len; s += per) ++made;
+            const uint32_t slot = hot_slot_of_row ? (uint32_t)(*hot_slot_of_row)[v.own] : 0u;
+            if (made >= (1 << 15)) throw std::invalid_argument("a row is cut into 2^15 chains or more in one block");
             for (long long s = 0; s < v.len; s += per)
-                visits.push_back({v.own, (uint32_t)std::min<long long>(per, v.len - s), v.start + (uint64_t)s});
+                visits.push_back({v.own, (uint32_t)std::min<long long>(per, v.len - s), v.start + (uint64_t)s,
+                                  hot_slot_of_row ? (uint32_t)made : 0u, slot, (uint32_t)(s / per)});
             out.hot++;
         } else {
             visits.push_back(v);
@@ -226,6 +238,21 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
     const char *ot = getenv("MFX_ONE_TASK");
     const int tasks_per_wave = ot && *ot ? atoi(ot) : cfg.task_steps > 0 ? 0 : per_wave < 128 ? 1 : 2;
     const int one_task = tasks_per_wave * std::max(1, cfg.waves_per_stripe);
+    // combine slots: one per owner row that is cut into chains in some block (row -> slot, -1 = none)
+    std::vector<int> hot_slot((size_t)(p.owner_is_q ? p.n : p.m), -1);
+    p.n_hot_slots = 0;
+    p.hot_rows.clear();
+    for (int b = 0; b < NB; ++b)
+        for (const Visit &v : block_visits[b])
+            if ((long long)v.len > hot_len && hot_slot[v.own] < 0) {
+                hot_slot[v.own] = (int)p.n_hot_slots++;
+                p.hot_rows.push_back((int)v.own);
+            }
+    if (p.n_hot_slots >= (1 << 20) || hot_len >= (1 << 12))
+        throw std::invalid_argument("too many hot rows / too long chains for the header entry format");
+    // experiment knob: round 1's behaviour (chains overwrite the row, the last writer wins: no headers, no fold)
+    const char *lww = getenv("MFX_HOT_LWW");
+    const bool hot_lww = lww && *lww && atoi(lww) != 0;
     std::vector<BlockPack> packs(NB);
     {
         std::vector<int> blocks(NB);
@@ -238,7 +265,8 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
             for (;;) {
                 int idx = next.fetch_add(1);
                 if (idx >= NB) break;
-                pack_visits(block_visits[blocks[idx]], G, target, hot_len, packs[blocks[idx]], one_task);
+                pack_visits(block_visits[blocks[idx]], G, target, hot_len, packs[blocks[idx]], one_task,
+                            hot_lww ? nullptr : &hot_slot);
             }
         };
         std::vector<std::thread> pool;
@@ -255,6 +283,7 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
         p.n_hot_rows += o.hot;
         p.n_padding += o.padding;
     }
+    p.headers.clear();
     p.tasks.clear();
     p.tasks.reserve(tot_t);
     places.clear();
@@ -272,10 +301,15 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
                 pl.dst += ebase;
                 places.push_back(pl);
             }
+            for (HeaderRec h : o.headers) {
+                h.dst += ebase;
+                p.headers.push_back(h);
+            }
             ebase += o.n_entries;
             p.slot_task_ptr[(size_t)r * NS + s + 1] = (long long)p.tasks.size();
             std::vector<TaskDesc>().swap(o.tasks);
             std::vector<Placement>().swap(o.places);
+            std::vector<HeaderRec>().swap(o.headers);
         }
     p.n_entries = (long long)ebase;
 }
@@ -498,6 +532,7 @@ void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cf
             }
         }
     });
+    for (const HeaderRec &h : p.headers) p.entries[h.dst] = header_entry(h);
 }
 
 void init_factors(const Plan &p, const int *omega_p_override, const int *omega_q_override,

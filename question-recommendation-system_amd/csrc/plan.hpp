@@ -26,8 +26,16 @@ static_assert(sizeof(Entry) == 12, "Entry must stay 12 bytes (mf_node sized)");
 struct TaskDesc { uint64_t off; uint32_t nsteps; uint32_t pad; };
 
 // All ratings of one owner row inside one block: `len` consecutive ratings of the block-sorted
-// rating array, starting at global index `start`.
-struct Visit { uint32_t own; uint32_t len; uint64_t start; };
+// rating array, starting at global index `start`.  A visit longer than the hot-chain length is cut into
+// `nch` chains (nch = 0: an ordinary visit); `hot` is then the row's combine slot (Plan::n_hot_slots).
+struct Visit { uint32_t own; uint32_t len; uint64_t start; uint32_t nch = 0; uint32_t hot = 0; uint32_t idx = 0; };
+
+// Header entry of a hot chain (written into the entry stream just before the chain's first rating):
+// entries[dst] = {own | bit 31, -(1 + (nch | idx << 15)), bits of `hot`}: nch chains of this row in this block
+// (2 <= nch < 2^15), this one is number idx in the order of the sorted visit; hot = combine slot (bits 0..19) |
+// chain length << 20.  The kernel gives every chain of a hot row its
+// own register copy and folds the chains' changes together when the last one of the launch ends.
+struct HeaderRec { uint64_t dst; uint32_t own; uint32_t nch; uint32_t hot; uint32_t idx; };
 
 // "Put sorted ratings [src, src+len) into entries[dst + x*G], x = 0..len-1, the first one flagged."
 struct Placement { uint64_t src; uint64_t dst; uint32_t len; uint32_t pad; };
@@ -36,6 +44,7 @@ struct Placement { uint64_t src; uint64_t dst; uint32_t len; uint32_t pad; };
 struct BlockPack {
     std::vector<TaskDesc> tasks;
     std::vector<Placement> places;
+    std::vector<HeaderRec> headers;
     uint64_t n_entries = 0;
     long long hot = 0, padding = 0;
 };
@@ -72,10 +81,25 @@ struct Plan {
     std::vector<Entry> entries;
     std::vector<TaskDesc> tasks;
     std::vector<long long> slot_task_ptr; // ns*ns+1, ordered (round, slot)
+    std::vector<HeaderRec> headers;       // hot-chain header entries (already part of `entries` on the host path)
+    long long n_hot_slots = 0;            // distinct rows that are cut into chains somewhere
+    std::vector<int> hot_rows;            // combine slot -> internal owner row
     long long n_entries = 0;   // entries.size() on the host path; on the device path the array lives in HBM only
     long long n_hot_rows = 0;
     long long n_padding = 0;
 };
+
+// the entry a header record stands for
+inline Entry header_entry(const HeaderRec &h)
+{
+    Entry e;
+    e.own = h.own | 0x80000000u;
+    e.gat = -(int32_t)(1u + (h.nch | (h.idx << 15))); // <= -3: nch >= 2 (a pad slot is -1)
+    uint32_t bits = h.hot;
+    static_assert(sizeof(float) == 4, "");
+    __builtin_memcpy(&e.r, &bits, 4);
+    return e;
+}
 
 // pieces shared by the host builder (build_plan) and the device builder (prep.hip)
 void plan_header(long long nnz, int m, int n, const PlanConfig &cfg, Plan &p);
@@ -97,7 +121,7 @@ inline int stripe_of(const int *begin, int ns, unsigned id)
     return lo;
 }
 void pack_visits(std::vector<Visit> &visits, int G, int target, int hot_len, BlockPack &out,
-                 int one_task_waves = 0);
+                 int one_task_waves = 0, const std::vector<int> *hot_slot_of_row = nullptr);
 void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig &cfg, Plan &p,
                  std::vector<Placement> &places, int threads);
 

@@ -167,6 +167,21 @@ __global__ __launch_bounds__(256) void emit_entries(const Placement *pl, long lo
     }
 }
 
+// header entries of the hot chains (plan.hpp: HeaderRec)
+__global__ __launch_bounds__(256) void emit_headers(const HeaderRec *h, long long nh, EntryD *entries)
+{
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nth = (long long)gridDim.x * blockDim.x;
+    for (long long i = tid; i < nh; i += nth) {
+        const HeaderRec r = h[i];
+        EntryD e;
+        e.own = r.own | 0x80000000u;
+        e.gat = -(int)(1u + (r.nch | (r.idx << 15)));
+        e.r = __uint_as_float(r.hot);
+        entries[r.dst] = e;
+    }
+}
+
 // ---- init_model on the device ----------------------------------------------------------------
 // The reference draws the initial factors from ONE std::minstd_rand0 stream, P rows then Q rows in
 // internal order, k draws per row that has ratings (mf.cpp:952-1007).  x_{i+1} = 16807 x_i mod (2^31-1)
@@ -388,6 +403,13 @@ void build_plan_device(const void *dR_v, long long nnz, int m, int n, const Plan
         hipLaunchKernelGGL(fill_entries, dim3(grid_of(p.n_entries, cu_count)), dim3(256), 0, s, dEntries, p.n_entries);
         hipLaunchKernelGGL(emit_entries, dim3(grid_of((long long)places.size(), cu_count)), dim3(256), 0, s,
                            dPlaces.p, (long long)places.size(), dKeyB.p, dValB.p, G, dEntries);
+        Buf<HeaderRec> dHeaders;
+        if (!p.headers.empty()) {
+            dHeaders.alloc(p.headers.size());
+            PREP_TRY(hipMemcpyAsync(dHeaders.p, p.headers.data(), p.headers.size() * sizeof(HeaderRec), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(emit_headers, dim3(grid_of((long long)p.headers.size(), cu_count)), dim3(256), 0, s,
+                               dHeaders.p, (long long)p.headers.size(), dEntries);
+        }
         PREP_TRY(hipGetLastError());
         PREP_TRY(hipStreamSynchronize(s));
     } catch (...) {

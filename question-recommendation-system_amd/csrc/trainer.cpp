@@ -97,6 +97,8 @@ struct mfx_trainer {
     DevBuf<long long> dSlotPtr;
     DevBuf<double> dEpochState; // zeroed once per epoch: LOSS_SLOTS loss sums, then the ns*ns task cursors
     int *dSlotStateP = nullptr;  // -> the cursors inside dEpochState
+    DevBuf<float> dHotAcc;   // combine slots of the hot rows (kernels.hip "hot chains")
+    DevBuf<int> dHotRow;     // combine slot -> internal owner row
     DevBuf<int> dSticky;     // raised by epoch_reset when an epoch left a block unfinished; never cleared
     DevBuf<double> dScalars; // [0..3] scratch for metrics
     double *dLossP = nullptr;    // -> the loss sums inside dEpochState
@@ -156,6 +158,8 @@ static int wgs_per_xcd_for(const mfx_options &opt, int m, int n, int ns, int cu_
     if (opt.wg_per_cu > 0) return opt.wg_per_cu * cu_per_xcd;
     int env = env_int("MFX_WG_PER_CU", 0);
     if (env > 0) return env * cu_per_xcd;
+    env = env_int("MFX_WGS_PER_XCD", 0); // experiment knob: exact launch width (1 = four waves per XCD)
+    if (env > 0) return env;
     const int ka = mfx::k_aligned(opt.k);
     const int G = 64 / mfx::lanes_for(ka);
     const bool owner_is_q = opt.owner_side == 0 ? (m >= n) : opt.owner_side == 2;
@@ -347,6 +351,16 @@ static int create_impl(const mfx::Node *R, const void *R_dev, long long nnz, int
         t->dLossP = t->dEpochState.p;
         t->dSlotStateP = (int *)(t->dEpochState.p + mfx::LOSS_SLOTS);
         HIP_TRY(t->dScalars.alloc(4));
+        {
+            const size_t slots = (size_t)std::max<long long>(1, p.n_hot_slots);
+            const size_t words = slots * (size_t)mfx::HOT_SUB * (size_t)(p.ka + mfx::HOT_EXTRA);
+            HIP_TRY(t->dHotAcc.alloc(words));
+            HIP_TRY(t->dHotRow.alloc(slots));
+            HIP_TRY(hipMemset(t->dHotAcc.p, 0, words * sizeof(float)));
+            HIP_TRY(hipMemset(t->dHotRow.p, 0, slots * sizeof(int)));
+            if (p.n_hot_slots > 0)
+                HIP_TRY(hipMemcpy(t->dHotRow.p, p.hot_rows.data(), (size_t)p.n_hot_slots * sizeof(int), hipMemcpyHostToDevice));
+        }
         HIP_TRY(t->dSticky.alloc(1));
         HIP_TRY(hipMemset(t->dSticky.p, 0, sizeof(int)));
         {
@@ -548,6 +562,7 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
     a.gat_rows = p.owner_is_q ? t->dP : t->dQ;
     a.own_acc = p.owner_is_q ? t->dQG : t->dPG;
     a.gat_acc = p.owner_is_q ? t->dPG : t->dQG;
+    a.hot_acc = t->dHotAcc.p;
     a.entries = t->dEntries.p;
     a.tasks = t->dTasks.p;
     a.loss = t->dLossP;
@@ -636,6 +651,9 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
         a.slot_task_ptr = t->dSlotPtr.p + (size_t)r * ns;
         a.slot_cursor = t->dSlotStateP + (size_t)r * ns;
         HIP_TRY(mfx::launch_sgd_round(p.lanes, a, grid, s));
+        // the chains of the hot owner rows of this round are folded into their rows (kernels.hip: fold_hot_rows)
+        HIP_TRY(mfx::launch_fold_hot(a.own_rows, a.own_acc, t->dHotAcc.p, t->dHotRow.p, (int)p.n_hot_slots, p.ka, a.eta,
+                                     a.rk1, a.slow_only, env_int("MFX_FOLD_MODE", 0), s));
     }
     if (e1) {
         HIP_TRY(hipEventRecord(e1, s));
@@ -1031,6 +1049,7 @@ int mfx_hostplan_view(const mfx_hostplan *h, mfx_plan_view *v)
     v->slot_task_ptr = p.slot_task_ptr.data();
     v->p_begin = p.p_begin.data();
     v->q_begin = p.q_begin.data();
+    v->n_hot_slots = p.n_hot_slots;
     return MFX_OK;
 }
 

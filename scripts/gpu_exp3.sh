@@ -1,0 +1,18 @@
+cd $GRAFT_REPO_ROOT; O=gpurun_out/exp3; mkdir -p $O; rm -f $O/log.txt
+timeout -k 5 200 python3 tests/tools/gpu_hot_debug.py 2>&1 | tail -14
+timeout -k 10 300 python3 tests/tools/gpu_hot_rows.py > $O/hot_rows.log 2>&1; cat $O/hot_rows.log
+run() { timeout -k 10 300 python3 scripts/gpu_case.py "$@" 2>&1 | grep CASE >> $O/log.txt || echo "FAILED $*" >> $O/log.txt; }
+for C in "c1 12" "c2s 12" "c2 8"; do
+  set -- $C
+  run $1 $2
+  run $1 $2
+  MFX_HOT_LWW=1 run $1 $2
+  MFX_WGS_PER_XCD=1 run $1 $2
+done
+cat $O/log.txt | python3 -c "
+import sys, json
+for l in sys.stdin:
+    if not l.startswith('CASE'): print(l.strip()); continue
+    d = json.loads(l[5:]); print('%-5s ep%2d %-22s %-50s %9.3f ms/epoch rmse %.4f wg/cu %d hot %d tasks %d' % (d['case'], d['epochs'], d['opts'], d['env'], d['ms_epoch'], d['rmse'], d['wg_per_cu'], d['hot'], d['tasks']))
+"
+python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -5 $O/pytest.log

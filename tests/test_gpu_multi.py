@@ -1,0 +1,108 @@
+"""GPU coverage of the N > 1 path on ONE card: two ranks (two processes on cuda:0) exchange item slots over gloo --
+the rehearsal path of multi.SlotRing, same schedule and bookkeeping as the RCCL path -- and the upper face of the
+boundary (libmfwarp.so's php_* thunks) executed at run time."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RMSE_RTOL = 0.02
+
+
+def _rank(rank, world, port, cfg, q):
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    spec = importlib.util.spec_from_file_location("qrs_multi", os.path.join(ge.PKG_DIR, "multi.py"))
+    multi = importlib.util.module_from_spec(spec); spec.loader.exec_module(multi)
+    pkg = ge.import_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m, n, nnz, k, iters, c = cfg
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+    stream = torch.cuda.current_stream().cuda_stream
+    R = torch.empty(nnz * 3, dtype=torch.int32, device=dev)
+    pkg.synth_device(3, 0, nnz, m, n, R.data_ptr(), None, shard=rank)  # this rank's users, the shared items
+    torch.cuda.synchronize()
+    t = multi.RotatingTrainer(pkg, R, m, n, world, rank, dist, dev, backend="gloo", slots_per_rank=c, k=k)
+    stripes = {x.info.stripes for x in t.trainers}
+    for it in range(iters):
+        t.epoch(slow_only=(it == 0), stream=stream)
+    t.sync()
+    got = t.rmse(all_ranks=True)
+    sizes = [x.info.nnz for x in t.trainers]
+    t.close()
+    dist.destroy_process_group()
+    q.put((rank, got, sorted(stripes), sizes))
+
+
+@pytest.mark.parametrize("c", [2, 1])
+def test_two_ranks_rotate_matches_oracle(pkg, orc, c):
+    """configs[3]'s shape scaled down (two user shards of one problem, items shared), trained by two ranks that pass
+    the item slots round the ring: final RMSE over ALL ratings vs the one-worker oracle on the union problem."""
+    import torch.multiprocessing as mp
+    world = 2
+    m, n, nnz, k, iters = 40000, 30000, 3000000, 32, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33000 + (os.getpid() * 3 + c) % 2000
+    procs = [ctx.Process(target=_rank, args=(r, world, port, (m, n, nnz, k, iters, c), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert res[0][1] == pytest.approx(res[1][1], rel=1e-9)         # both ranks report the job-wide figure
+    assert res[0][2] == res[1][2] and len(res[0][2]) == 1          # ONE stripe count for the whole job
+    assert sum(res[0][3]) == nnz and sum(res[1][3]) == nnz         # every rating sits in exactly one slot trainer
+    # the union problem for the oracle: rank r's users are rows [r*m, (r+1)*m)
+    parts = []
+    for r in range(world):
+        Rr = pkg.synth_host(3, 0, nnz, m, n, shard=r)
+        Rr["u"] += r * m
+        parts.append(Rr)
+    R = np.concatenate(parts)
+    want = orc.rmse(R, orc.train(R, world * m, n, k=k, iters=iters))
+    got = res[0][1]
+    assert abs(got - want) / want < RMSE_RTOL, (got, want)
+
+
+def test_php_face_runs(pkg, orc, toy, capfd):
+    """The upper face at run time: php_utility_train -> php_utility_predict of lib/libmfwarp.so
+    (reference php_mf/mfWarp.cpp:12-22) on mfTest.cpp's triples, same assertions as the mf:: facade test."""
+    L = C.CDLL(pkg.WARP_PATH)
+    L.php_utility_train.restype = C.POINTER(C.c_float)
+    L.php_utility_train.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int)]
+    L.php_utility_predict.restype = C.POINTER(C.c_float)
+    L.php_utility_predict.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]
+    tr = np.ascontiguousarray(toy["train"], dtype=np.float32)
+    lens = C.c_int(0)
+    p = L.php_utility_train(tr.ctypes.data, len(tr) // 3, 0.1, 0.1, 8, 30, 0.1, C.byref(lens))
+    table = capfd.readouterr().out.splitlines()
+    assert p and lens.value == 5 + 3 * 8 + 4 * 8
+    arr = np.ctypeslib.as_array(p, (lens.value,)).copy()
+    assert arr[:5].tolist() == [0.0, 3.0, 4.0, 8.0, 4.75]
+    assert table[0].split() == ["iter", "tr_rmse", "obj"] and len(table) == 31 and table[30].split()[0] == "29"
+    te = np.ascontiguousarray(toy["test"], dtype=np.float32)
+    pp = L.php_utility_predict(te.ctypes.data, len(te) // 2, arr.ctypes.data, len(arr))
+    assert pp
+    pred = np.ctypeslib.as_array(pp, (len(te) // 2,)).copy()
+    libc.free(p); libc.free(pp)  # malloc'd by the callee (reference mf/mf.cpp:3426, 3561)
+    t = tr.reshape(-1, 3)
+    R = pkg.as_nodes(t[:, 0], t[:, 1], t[:, 2])
+    assert abs(orc.rmse(R, arr) - float(toy["rmse"])) < 0.03
+    np.testing.assert_allclose(pred[:8], toy["pred"][:8], atol=0.15)
+    np.testing.assert_allclose(pred, pkg.utility_predict(te, arr), rtol=0, atol=0)  # same path as the mf:: face
+    # bad input through the upper face: NULL and lens = 0, no crash (the reference dereferences null, mf.cpp:3312-3313)
+    lens = C.c_int(7)
+    assert not L.php_utility_train(tr.ctypes.data, 0, 0.1, 0.1, 8, 30, 0.1, C.byref(lens)) and lens.value == 0

@@ -46,7 +46,8 @@ def check_plan(pkg, orc, R, m, n, k, **kw):
     NS, G = v.stripes, v.ratings_per_wave
     assert G * v.lanes_per_rating == 64 and v.lanes_per_rating * 4 >= v.k_aligned
     act = e["gat"] >= 0
-    assert act.sum() == len(R) and v.n_padding == len(e) - len(R)
+    hdr = e["gat"] < -1  # header entries of hot chains: {row | bit 31, -(1 + chains of the row in this launch), slot}
+    assert act.sum() == len(R) and v.n_padding == len(e) - len(R) - hdr.sum()
     # every rating exactly once, relabelled and scaled exactly as shuffle/scale_problem do
     Ri = internal(R, hp, orc)
     own = (e["own"][act] & 0x7FFFFFFF).astype(np.int64)
@@ -86,11 +87,32 @@ def check_plan(pkg, orc, R, m, n, k, **kw):
         off, ns = int(tasks["off"][ti]), int(tasks["nsteps"][ti])
         blk = e[off: off + ns * G].reshape(ns, G)
         for g in range(G):
-            col = blk[:, g]; a = col["gat"] >= 0
+            col = blk[:, g]; a = col["gat"] >= 0; pad = col["gat"] == -1
             ids = (col["own"][a] & 0x7FFFFFFF); fl = (col["own"][a] >> 31).astype(bool)
             if len(ids):
                 assert fl[0] and (fl[1:] | (ids[1:] == ids[:-1])).all()
-                assert not a[np.argmax(~a):].any() if (~a).any() else True  # padding only at the tail
+                assert not (~pad)[np.argmax(pad):].any() if pad.any() else True  # padding only at the tail
+            # a header is followed by the first rating of its chain: same row, reload flag set
+            for i in np.nonzero(col["gat"] < -1)[0]:
+                assert col["own"][i] >> 31 and i + 1 < ns and col["gat"][i + 1] >= 0
+                assert col["own"][i + 1] == col["own"][i]
+    # hot chains: within one launch (round) a row's headers all carry the same chain count, and there are exactly
+    # that many of them -- the kernel's last-chain test counts on it; a row keeps ONE combine slot everywhere
+    slot_of = {}
+    for r in range(NS):
+        t0, t1 = sptr[r * NS], sptr[(r + 1) * NS]
+        if t0 == t1:
+            continue
+        lo = int(tasks["off"][t0]); hi = int(tasks["off"][t1 - 1]) + int(tasks["nsteps"][t1 - 1]) * G
+        h = e[lo:hi][e["gat"][lo:hi] < -1]
+        rows, cnt = np.unique(h["own"] & 0x7FFFFFFF, return_counts=True)
+        for row, c in zip(rows, cnt):
+            mine = h[(h["own"] & 0x7FFFFFFF) == row]
+            code = -mine["gat"].astype(np.int64) - 1  # chains | index << 15
+            assert ((code & 0x7FFF) == c).all() and c >= 2 and sorted(code >> 15) == list(range(c))
+            slot = set((mine["r"].view(np.uint32) & 0xFFFFF).tolist())
+            assert len(slot) == 1 and slot_of.setdefault(int(row), slot) == slot
+    assert len({tuple(s) for s in slot_of.values()}) == len(slot_of)  # distinct rows, distinct slots
     return hp
 
 

@@ -54,3 +54,110 @@ def test_two_rank_sharding_and_averaging():
         p.join(180)
         assert p.exitcode == 0
     assert sorted(q.get() for _ in range(world)) == [0, 1]
+
+
+# ---- the slot ring of the rotation scheme (multi.SlotRing) with a counting "trainer" ---------------------
+
+def _load_multi():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("qrs_multi", os.path.join(ge.PKG_DIR, "multi.py"))
+    multi = importlib.util.module_from_spec(spec); spec.loader.exec_module(multi)
+    return multi
+
+
+def _ring_worker(rank, world, port, c, epochs, q):
+    multi = _load_multi()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S, E = c * world, 5
+    buf = torch.zeros(S * E)
+    ring = multi.SlotRing(buf, E, world, rank, dist, backend="gloo", c=c)
+    log = []
+
+    def train(s):  # "training" = count it, remember who and when; v[3] = running checksum of (rank, step) pairs
+        v = ring.view(s)
+        log.append((ring.t, s, int(v[0])))
+        v[0] += 1; v[1] = rank; v[2] = ring.t; v[3] = v[3] * 3 + rank + 1; v[4] = s
+
+    for _ in range(epochs * S):
+        ring.step(train)
+    fresh = sorted(ring.fresh_slots())
+    ring.gather_fresh()
+    dist.destroy_process_group()
+    q.put((rank, log, fresh, buf.clone().numpy()))
+
+
+def _run_ring(world, c, epochs=3):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + (os.getpid() * 7 + world * 13 + c) % 2000
+    procs = [ctx.Process(target=_ring_worker, args=(r, world, port, c, epochs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return {r: (log, fresh, buf) for r, log, fresh, buf in res}
+
+
+def _check_ring(world, c, epochs=3):
+    S = c * world
+    res = _run_ring(world, c, epochs)
+    trained = {}  # (step, slot) -> rank
+    for r, (log, fresh, buf) in res.items():
+        # every window of S steps visits every slot exactly once
+        for e in range(epochs):
+            assert sorted(s for t, s, _ in log[e * S:(e + 1) * S]) == list(range(S))
+        for t, s, _cnt in log:
+            assert (t, s) not in trained, "two ranks trained slot %d at step %d" % (s, t)  # one writer per slot at any time
+            trained[(t, s)] = r
+    # no two ranks hold the same slot at the same step (the scheduler's rule, reference mf/mf.cpp:133-141), and the slot a
+    # rank trains always carries EVERY training done before that step, by whichever rank: the ring never hands on a stale copy
+    for r, (log, fresh, buf) in res.items():
+        for t, s, cnt in log:
+            before = sum(1 for (t2, s2) in trained if s2 == s and t2 < t)
+            assert cnt == before, (r, t, s, cnt, before)
+    # after gather_fresh every rank sees every slot at its final state; the fresh slots of the ranks tile the slot set
+    allfresh = sorted(s for r in res for s in res[r][1])
+    assert allfresh == list(range(S))
+    ref = res[0][2].reshape(S, -1)
+    for r in res:
+        b = res[r][2].reshape(S, -1)
+        assert (b[:, 0] == epochs * world).all() and np.array_equal(b, ref)
+        assert b[:, 4].tolist() == list(range(S))
+
+
+def test_slot_ring_two_ranks_overlapped():
+    """c = 2: the transfer of the slot trained at step t-1 runs beside step t; 2 gloo ranks."""
+    _check_ring(2, 2)
+
+
+def test_slot_ring_two_ranks_plain():
+    """c = 1: train, then shift (round 1's ring)."""
+    _check_ring(2, 1)
+
+
+def test_slot_ring_three_ranks_overlapped():
+    _check_ring(3, 2, epochs=2)
+
+
+def test_stripe_count_is_pinned_per_job():
+    """The id layout depends on the stripe count (balanced_map deals heavy rows per stripe), so trainers that share
+    rows must not choose it from their own nnz: pieces straddling the small-problem threshold would disagree.
+    mfx_stripes_for is what RotatingTrainer evaluates ONCE on the smallest piece of the job."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    pkg = ge.import_package()
+    o = pkg.default_options(k=32)
+    m, n = 100000, 16667
+    lo, hi = pkg.stripes_for(o, 3050000, m, n), pkg.stripes_for(o, 3300000, m, n)
+    assert (lo, hi) == (4, 8)  # the two pieces of ADVICE's example would have chosen different grids
+    R = pkg.synth_host(1, 0, 3300000, m, n)
+    a = pkg.HostPlan(R[:3050000], m, n, opts=pkg.default_options(k=32, stripes=lo))
+    b = pkg.HostPlan(R, m, n, opts=pkg.default_options(k=32, stripes=lo))
+    assert a.view.stripes == b.view.stripes == lo  # an explicit stripe count wins over the size heuristic
+    o.stripes = 8
+    assert pkg.stripes_for(o, 1000, m, n) == 8
