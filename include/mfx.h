@@ -158,6 +158,12 @@ int mfx_trainer_export(mfx_trainer *t, float *model_arr, long long len);
  * device: pairs = (u,v) as floats, out = float[npairs].  Host buffers. */
 int mfx_predict_array(const float *model_arr, long long model_len, const float *pairs,
                       long long npairs, float *out);
+/* The model array of the last mfx_predict_array / mfx_rmse_array call stays resident in HBM (the reference's
+ * array_to_model copies the whole model per call, mf.cpp:3444-3481, 3537-3568): a call with the same host
+ * pointer, length, header and sampled checksum skips the upload.  _drop releases it (call it after changing an
+ * array in place); _stats counts uploads and hits since process start.  MFX_PREDICT_CACHE=0 disables the reuse. */
+void mfx_predict_cache_drop(void);
+void mfx_predict_cache_stats(long long *uploads, long long *hits);
 /* calc_rmse (mf.cpp:4316-4331) of a facade array on host ratings, on the device. */
 int mfx_rmse_array(const float *model_arr, long long model_len, const mfx_node *R,
                    long long nnz, double *rmse);

@@ -98,6 +98,10 @@ def ref():
         L.ref_utility_predict.argtypes = [vp, i32, vp, i32]
         L.ref_time_train.restype = C.c_double
         L.ref_time_train.argtypes = [vp, ll, i32, i32, i32, i32, i32, i32, f32, f32, f32, C.POINTER(C.c_double)]
+        L.ref_cos_similarity.restype = C.POINTER(f32)
+        L.ref_cos_similarity.argtypes = [i32, vp, i32]
+        L.ref_DINA.restype = C.POINTER(i32)
+        L.ref_DINA.argtypes = [vp, i32, vp, i32, i32]
         L.ref_free.argtypes = [vp]
         _ref = L
     return _ref
@@ -323,6 +327,29 @@ def ref_call(op, R, m, n, k, iters, threads, bins, lambda_p=0.1, lambda_q=0.1, e
             raise RuntimeError("reference worker failed: %s" % err.decode(errors="replace")[-2000:])
     raise RefHang("reference %s did not return in %.0f s on %d attempts (shutdown race, quirk Q2)"
                   % (op, timeout, attempts))
+
+
+def ref_extras(q_arr, x_arr, items, users, skills, dina_iters=(2, 6, 20), timeout=60):
+    """The reference's mf::cos_similarity for every item and mf::DINA for a few iteration counts, each DINA call in a
+    FRESH child process (its start values come from the process-global rand(), reference mf/mf.cpp:3759)."""
+    import sys
+    import tempfile
+    out = {}
+    with tempfile.TemporaryDirectory(prefix="refcall_") as d:
+        for it in (None,) + tuple(dina_iters):
+            inp, outp = os.path.join(d, "in.npz"), os.path.join(d, "out.npz")
+            if os.path.exists(outp):
+                os.remove(outp)
+            np.savez(inp, op=np.array("cos" if it is None else "dina"), q=np.asarray(q_arr, dtype=np.float32),
+                     x=np.asarray(x_arr, dtype=np.float32), cfg=np.array([items, users, skills, it or 0, 0, 0]),
+                     hyper=np.zeros(3))
+            subprocess.run([sys.executable, os.path.join(_HERE, "ref_worker.py"), inp, outp], check=True, timeout=timeout)
+            with np.load(outp) as z:
+                if it is None:
+                    out["cos"] = z["cos"]
+                else:
+                    out["dina_%d" % it] = z["dina"]
+    return out
 
 
 def ref_train(R, m, n, k=8, iters=20, threads=1, bins=20, lambda_p=0.1, lambda_q=0.1, eta=0.1,

@@ -85,6 +85,14 @@ double ref_time_train(const mf::mf_node *R, long long nnz, int m, int n, int k,
                       int nr_threads, int nr_bins, int nr_iters, float lambda_p2,
                       float lambda_q2, float eta, double *rmse_out);
 
+// mf::cos_similarity (mf.cpp:3591-3683) and mf::DINA (mf.cpp:3685-4109) as they stand.  DINA draws its start
+// values from the process-global rand() (mf.cpp:3759): call it in a fresh process for a defined result.
+float *ref_cos_similarity(int item_id, float *q_arr, int q_arr_num) { return mf::cos_similarity(item_id, q_arr, q_arr_num); }
+int *ref_DINA(float *q_arr, int q_triplet_num, float *x_arr, int x_triplet_num, int iterators)
+{
+    return mf::DINA(q_arr, q_triplet_num, x_arr, x_triplet_num, iterators);
+}
+
 void ref_free(void *p) { free(p); }
 }
 

@@ -28,6 +28,18 @@ def main():
     elif op == "time":
         secs, rm = orc._ref_time_inproc(R, m, n, k, iters, threads, bins, lp, lq, eta)
         np.savez(outp, secs=np.array([secs]), rmse=np.array([rm]))
+    elif op == "cos":  # mf::cos_similarity for every item (m = items)
+        q = np.ascontiguousarray(a["q"], dtype=np.float32)
+        rows = []
+        for item in range(m):
+            p = orc.ref().ref_cos_similarity(item, q.ctypes.data, len(q) // 3)
+            rows.append(np.ctypeslib.as_array(p, (m,)).copy())
+        np.savez(outp, cos=np.stack(rows))
+    elif op == "dina":  # mf::DINA once per process: n = users, k = skills, iters = iterators
+        q = np.ascontiguousarray(a["q"], dtype=np.float32)
+        x = np.ascontiguousarray(a["x"], dtype=np.float32)
+        p = orc.ref().ref_DINA(q.ctypes.data, len(q) // 3, x.ctypes.data, len(x) // 3, iters)
+        np.savez(outp, dina=np.ctypeslib.as_array(p, (n * k,)).copy())
     else:
         raise SystemExit("unknown op " + op)
 

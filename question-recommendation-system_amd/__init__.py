@@ -109,6 +109,9 @@ def lib():
     L.mfx_trainer_export.argtypes = [vp, vp, ll]
     L.mfx_predict_array.argtypes = [vp, ll, vp, ll, vp]
     L.mfx_rmse_array.argtypes = [vp, ll, vp, ll, C.POINTER(C.c_double)]
+    L.mfx_predict_cache_drop.restype = None
+    L.mfx_predict_cache_stats.argtypes = [C.POINTER(ll), C.POINTER(ll)]
+    L.mfx_predict_cache_stats.restype = None
     L.mfx_hostplan_build.argtypes = [vp, ll, i32, i32, C.POINTER(Options), C.POINTER(vp)]
     L.mfx_hostplan_view.argtypes = [vp, C.POINTER(PlanView)]
     L.mfx_hostplan_init_factors.argtypes = [vp, vp, vp]
@@ -218,6 +221,17 @@ def predict_array(model, pairs):
     out = np.empty(len(t) // 2, dtype=np.float32)
     _check(lib().mfx_predict_array(mdl.ctypes.data, len(mdl), t.ctypes.data, len(t) // 2, out.ctypes.data))
     return out
+
+
+def predict_cache_stats():
+    """(uploads, hits) of the device-resident model array of utility_predict (mfx_predict_cache_stats)."""
+    u, h = C.c_longlong(), C.c_longlong()
+    lib().mfx_predict_cache_stats(C.byref(u), C.byref(h))
+    return u.value, h.value
+
+
+def predict_cache_drop():
+    lib().mfx_predict_cache_drop()
 
 
 def rmse_array(model, R):

@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
 // 2 eta / (sqrt(G_end) + sqrt(G0))), the curvature |q|^2 from the accumulator growth over the squared errors
 // (A = rk * sum e^2 |q|^2): nothing extra is computed per rating.
 __global__ __launch_bounds__(256) void fold_hot_rows(float *rows, float *acc, float *hot_acc, const int *hot_row,
-                                                     int n_slots, int ka, float eta, float rk1, int slow_only, int fold_mode)
+                                                     int n_slots, int ka, float eta, float rk1, int slow_only, int fold_mode, float s_gain)
 {
     const int lane = threadIdx.x & 63;
     const int slot_i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void fold_hot_rows(float *rows, float *acc, fl
     // the same unmoved value, so the error shrinks faster than the row's own curvature says; the factor was calibrated
     // on the order emulation (oracle/plan_order.c: final RMSE of the plan's order with chains vs without, three data
     // sets within +-0.4 %; tests/tools/order_study.py)
-    const float phi = damp(HOT_S_GAIN * Sseq) / damp(HOT_S_GAIN * Sch); // (1-exp(-S)) / (n (1-exp(-S/n))) in the symmetric case
+    const float phi = damp(s_gain * Sseq) / damp(s_gain * Sch); // (1-exp(-S)) / (n (1-exp(-S/n))) in the symmetric case
     // fold_mode 0: the damped sum above; 1 (experiment): the row becomes the MEAN of the chains' end states
     const float sc0 = fold_mode == 1 ? rn : phi * ts0 / tc0, sc1 = fold_mode == 1 ? rn : phi * ts1 / tc1;
     for (int d = lane; d < (slow_only ? 8 : ka); d += 64) { // (epoch 0 moves the first eight factors only)
@@ -799,11 +799,11 @@ hipError_t launch_sgd_round(int lanes, const RoundArgs &a, int grid, hipStream_t
 }
 
 hipError_t launch_fold_hot(float *rows, float *acc, float *hot_acc, const int *hot_row, int n_slots, int ka, float eta,
-                           float rk1, int slow_only, int fold_mode, hipStream_t s)
+                           float rk1, int slow_only, int fold_mode, float s_gain, hipStream_t s)
 {
     if (n_slots <= 0) return hipSuccess;
     hipLaunchKernelGGL(fold_hot_rows, dim3((n_slots + 3) / 4), dim3(256), 0, s, rows, acc, hot_acc, hot_row, n_slots, ka,
-                       eta, rk1, slow_only, fold_mode);
+                       eta, rk1, slow_only, fold_mode, s_gain);
     return hipGetLastError();
 }
 

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -165,7 +166,7 @@ static int wgs_per_xcd_for(const mfx_options &opt, int m, int n, int ns, int cu_
     const bool owner_is_q = opt.owner_side == 0 ? (m >= n) : opt.owner_side == 2;
     const long long n_gat = owner_is_q ? m : n;
     const long long stripe_rows = (n_gat + ns - 1) / ns;
-    const int div = std::max(1, env_int("MFX_CONFLICT_DIV", 8));
+    const int div = std::max(1, env_int("MFX_CONFLICT_DIV", 12));
     long long waves = stripe_rows / ((long long)div * G);
     // Small stripes: the head of the popularity distribution weighs more the fewer rows share a
     // stripe, and the RMSE gap to the sequential reference grows (+2.0..2.9 % at 2500 rows per stripe,
@@ -653,7 +654,8 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
         HIP_TRY(mfx::launch_sgd_round(p.lanes, a, grid, s));
         // the chains of the hot owner rows of this round are folded into their rows (kernels.hip: fold_hot_rows)
         HIP_TRY(mfx::launch_fold_hot(a.own_rows, a.own_acc, t->dHotAcc.p, t->dHotRow.p, (int)p.n_hot_slots, p.ka, a.eta,
-                                     a.rk1, a.slow_only, env_int("MFX_FOLD_MODE", 0), s));
+                                     a.rk1, a.slow_only, env_int("MFX_FOLD_MODE", 0),
+                                     (float)env_int("MFX_HOT_S_GAIN", (int)mfx::HOT_S_GAIN), s));
     }
     if (e1) {
         HIP_TRY(hipEventRecord(e1, s));
@@ -916,6 +918,89 @@ static int parse_header(const float *a, long long len, int &m, int &n, int &k, f
     return MFX_OK;
 }
 
+// ---- the model array of utility_predict, kept on the device ----------------------------------------------
+// The reference rebuilds the model from the float array on every call (array_to_model, mf/mf.cpp:3444-3481) and
+// so did round 1 here: one H2D copy of the whole array per call (384 MB for configs[2]).  A PHP request loop
+// calls utility_predict again and again with the SAME array, so the last array stays resident, keyed by host
+// pointer, length, header and a checksum over 16 K evenly spaced words -- hashing every word would cost more
+// than the copy it saves.  An array changed in place between two calls at none of the sampled words would be
+// missed: callers that do that call mfx_predict_cache_drop() (or set MFX_PREDICT_CACHE=0).
+namespace {
+struct ModelCache {
+    std::mutex mu;
+    const float *host = nullptr;
+    long long len = 0;
+    unsigned long long sum = 0;
+    float header[5] = {0, 0, 0, 0, 0};
+    int device = -1;
+    float *dev = nullptr;
+    hipStream_t stream = nullptr;
+    long long uploads = 0, hits = 0;
+} g_model_cache;
+
+unsigned long long sample_sum(const float *a, long long len)
+{
+    const long long samples = 16384, step = len > samples ? len / samples : 1;
+    unsigned long long h = 1469598103934665603ull;
+    for (long long i = 0; i < len; i += step) {
+        unsigned w;
+        memcpy(&w, a + i, 4);
+        h = (h ^ w) * 1099511628211ull;
+    }
+    unsigned w;
+    memcpy(&w, a + len - 1, 4);
+    return (h ^ w) * 1099511628211ull;
+}
+
+// device copy of the model array on the current device (cached); *stream = the cache's stream
+int resident_model(const float *model_arr, long long model_len, float **d_model, hipStream_t *stream)
+{
+    ModelCache &c = g_model_cache;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (!c.stream) HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    const bool use = env_int("MFX_PREDICT_CACHE", 1) != 0;
+    const unsigned long long sum = sample_sum(model_arr, model_len);
+    if (use && c.dev && c.host == model_arr && c.len == model_len && c.device == dev && c.sum == sum &&
+        memcmp(c.header, model_arr, sizeof(c.header)) == 0) {
+        c.hits++;
+    } else {
+        if (c.dev && (c.len != model_len || c.device != dev)) {
+            (void)hipFree(c.dev);
+            c.dev = nullptr;
+        }
+        if (!c.dev) HIP_TRY(hipMalloc((void **)&c.dev, (size_t)model_len * 4));
+        c.host = nullptr; // not valid until the copy is through
+        HIP_TRY(hipMemcpyAsync(c.dev, model_arr, (size_t)model_len * 4, hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        c.host = model_arr;
+        c.len = model_len;
+        c.sum = sum;
+        c.device = dev;
+        memcpy(c.header, model_arr, sizeof(c.header));
+        c.uploads++;
+    }
+    *d_model = c.dev;
+    *stream = c.stream;
+    return MFX_OK;
+}
+} // namespace
+
+void mfx_predict_cache_drop(void)
+{
+    std::lock_guard<std::mutex> lock(g_model_cache.mu);
+    if (g_model_cache.dev) (void)hipFree(g_model_cache.dev);
+    g_model_cache.dev = nullptr;
+    g_model_cache.host = nullptr;
+}
+
+void mfx_predict_cache_stats(long long *uploads, long long *hits)
+{
+    std::lock_guard<std::mutex> lock(g_model_cache.mu);
+    if (uploads) *uploads = g_model_cache.uploads;
+    if (hits) *hits = g_model_cache.hits;
+}
+
 int mfx_predict_array(const float *model_arr, long long model_len, const float *pairs,
                       long long npairs, float *out)
 {
@@ -932,16 +1017,18 @@ int mfx_predict_array(const float *model_arr, long long model_len, const float *
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
-    DevBuf<float> dModel, dPairs, dOut;
-    HIP_TRY(dModel.alloc((size_t)model_len));
+    std::lock_guard<std::mutex> lock(g_model_cache.mu);
+    float *dModel = nullptr;
+    hipStream_t s = nullptr;
+    if (int rc2 = resident_model(model_arr, model_len, &dModel, &s)) return rc2;
+    DevBuf<float> dPairs, dOut;
     HIP_TRY(dPairs.alloc((size_t)npairs * 2));
     HIP_TRY(dOut.alloc((size_t)npairs));
-    HIP_TRY(hipMemcpy(dModel.p, model_arr, (size_t)model_len * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dPairs.p, pairs, (size_t)npairs * 8, hipMemcpyHostToDevice));
-    HIP_TRY(mfx::launch_predict(dModel.p, m, n, k, b, dPairs.p, npairs, dOut.p,
-                                grid_for(npairs * 16, prop.multiProcessorCount), nullptr));
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, dOut.p, (size_t)npairs * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(dPairs.p, pairs, (size_t)npairs * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(mfx::launch_predict(dModel, m, n, k, b, dPairs.p, npairs, dOut.p,
+                                grid_for(npairs * 16, prop.multiProcessorCount), s));
+    HIP_TRY(hipMemcpyAsync(out, dOut.p, (size_t)npairs * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return MFX_OK;
 }
 
@@ -964,20 +1051,21 @@ int mfx_rmse_array(const float *model_arr, long long model_len, const mfx_node *
         return fail(MFX_E_HIP, "no HIP device: the MI355X path cannot run (there is no CPU fallback)");
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
-    DevBuf<float> dModel;
+    std::lock_guard<std::mutex> lock(g_model_cache.mu);
+    float *dModel = nullptr;
+    hipStream_t st = nullptr;
+    if (int rc2 = resident_model(model_arr, model_len, &dModel, &st)) return rc2;
     DevBuf<mfx::EntryD> dR;
     DevBuf<double> dS;
-    HIP_TRY(dModel.alloc((size_t)model_len));
     HIP_TRY(dR.alloc((size_t)nnz));
     HIP_TRY(dS.alloc(1));
-    HIP_TRY(hipMemcpy(dModel.p, model_arr, (size_t)model_len * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dR.p, R, (size_t)nnz * 12, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(dS.p, 0, sizeof(double)));
-    HIP_TRY(mfx::launch_sq_err_nodes(dModel.p, m, n, k, b, dR.p, nnz, dS.p,
-                                     grid_for(nnz * 16, prop.multiProcessorCount), nullptr));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyAsync(dR.p, R, (size_t)nnz * 12, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(dS.p, 0, sizeof(double), st));
+    HIP_TRY(mfx::launch_sq_err_nodes(dModel, m, n, k, b, dR.p, nnz, dS.p,
+                                     grid_for(nnz * 16, prop.multiProcessorCount), st));
     double s = 0;
-    HIP_TRY(hipMemcpy(&s, dS.p, sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(&s, dS.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     *rmse = std::sqrt(s / (double)nnz);
     return MFX_OK;
 }

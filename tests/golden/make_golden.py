@@ -57,5 +57,23 @@ def main():
     np.savez_compressed(os.path.join(HERE, "small.npz"), **cases)
 
 
+Q_ARR = np.array([0,0,1, 0,1,-1, 0,2,-1, 0,3,-1, 0,4,-1, 1,0,-1, 1,1,1, 1,2,-1, 1,3,1, 1,4,-1,
+                  2,0,-1, 2,1,-1, 2,2,-1, 2,3,-1, 2,4,1, 3,0,1, 3,1,-1, 3,2,1, 3,3,1, 3,4,-1,
+                  4,0,1, 4,1,-1, 4,2,1, 4,3,-1, 4,4,-1], dtype=np.float32)  # reference mfTest/mfTest.cpp:28-52
+X_ARR = np.array([0,0,1, 0,1,0, 0,2,1, 0,3,0, 0,4,1, 1,0,1, 1,1,0, 1,2,1, 1,3,1, 1,4,0,
+                  2,0,1, 2,1,0, 2,2,0, 2,3,0, 2,4,1, 3,0,0, 3,1,0, 3,2,1, 3,3,0, 3,4,1], dtype=np.float32)  # :53-73
+
+
+def extras():
+    """3. mf::cos_similarity / mf::DINA of the reference on mfTest.cpp's Q and X matrices -> extras.npz"""
+    res = orc.ref_extras(Q_ARR, X_ARR, items=5, users=4, skills=5, dina_iters=(2, 3, 6, 20))
+    np.savez(os.path.join(HERE, "extras.npz"), q=Q_ARR, x=X_ARR, **res)
+    for key, val in res.items():
+        print(key, val.reshape(val.shape[0], -1) if val.ndim > 1 else val)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "extras":
+        extras()
+        raise SystemExit(0)
     main()

@@ -32,3 +32,22 @@ def test_dina_shape_and_determinism(pkg):
     assert np.array_equal(a, b) and set(a.tolist()) <= {0, 1}  # 4 students x 5 skills, binary mastery
     c = np.ctypeslib.as_array(f(Q_ARR.ctypes.data, 25, X_ARR.ctypes.data, 20, 6), (20,)).copy()
     assert set(c.tolist()) <= {0, 1}
+
+
+def test_extras_match_reference_golden(pkg):
+    """mf::cos_similarity / mf::DINA against what the REFERENCE returned for the same matrices (tests/golden/extras.npz,
+    recorded by tests/golden/make_golden.py extras from oracle/_ref, each DINA call in a fresh process because its start
+    values come from the process-global rand(), reference mf/mf.cpp:3759 -- this library draws the same glibc sequence
+    from a private generator).  mfTest.cpp's matrices name every cell, so the reference's uninitialised cells
+    (mf.cpp:3605-3618) do not come into it."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "extras.npz"))
+    q, x = np.ascontiguousarray(g["q"]), np.ascontiguousarray(g["x"])
+    cos = getattr(pkg.lib(), pkg.MANGLED["cos_similarity"])
+    for item in range(5):
+        got = np.ctypeslib.as_array(cos(item, q.ctypes.data, 25), (5,)).copy()
+        assert np.array_equal(got, g["cos"][item]), (item, got, g["cos"][item])
+    dina = getattr(pkg.lib(), pkg.MANGLED["DINA"])
+    for it in (2, 3, 6, 20):
+        got = np.ctypeslib.as_array(dina(q.ctypes.data, 25, x.ctypes.data, 20, it), (20,)).copy()
+        assert np.array_equal(got, g["dina_%d" % it]), (it, got, g["dina_%d" % it])

@@ -3,17 +3,24 @@
 Tolerances (floating point; the path is lock-free and its update order differs from the
 reference's, which is itself order-dependent -- SURVEY.md 3.4 Q2/Q3, 8d):
   * one conflict-free pass of the kernel vs orc_sgd_one, same inputs:   1e-5 relative
-  * training, same triples / epochs / hyper-parameters: final training RMSE within
-    RMSE_RTOL = 2 % of the oracle's from 5 M ratings up, 3 % below (a stripe then holds only a
-    few hundred to a few thousand rows and the run-to-run spread of the lock-free path grows);
-    measured over 23 shape/width/seed cases: -1.4 % .. +2.0 % (profiles/experiments/r01_parity_sweep.md)
+  * training, same triples / epochs / hyper-parameters: final training RMSE (calc_rmse formula) within
+    RMSE_RTOL = 2.5 % of the one-worker oracle's.  ONE number, used by every training test here, by
+    tests/test_gpu_multi.py, bench.py and README/DESIGN.md.  Where it comes from: the oracle
+    itself moves by +-1 % with nr_bins / block order alone; the GPU plan's order of the same arithmetic
+    (oracle/plan_order.c) sits -0.6 .. -1.9 % from the reference's order at 12 epochs, where the curve still
+    falls 2 % per epoch; the lock-free execution adds -1.3 .. +1.6 %.
+  * GPU vs the oracle's arithmetic walked in the GPU plan's own order (plan_order.c): 2 %
   * predictions / calc_rmse from the same model array:                   1e-5 relative
 """
+import json
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-RMSE_RTOL = 0.02
+RMSE_RTOL = 0.025
+FULL = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size.json")))
 
 
 def internal(R, t):
@@ -72,15 +79,15 @@ def test_rk_fast_switch(pkg, orc):
     t.close()
 
 
-TRAIN_CASES = [  # m, n, nnz, k, iters, tolerance
-    (2000, 1500, 120000, 16, 8, 0.03), (3000, 2000, 100000, 8, 8, 0.03), (3000, 2000, 100000, 40, 6, 0.03),
-    (20000, 10000, 2000000, 32, 10, 0.03), (20000, 10000, 2000000, 64, 6, 0.03),
-    (5000, 4000, 400000, 128, 5, 0.03), (60000, 30000, 6000000, 32, 8, RMSE_RTOL),
+TRAIN_CASES = [  # m, n, nnz, k, iters
+    (2000, 1500, 120000, 16, 8), (3000, 2000, 100000, 8, 8), (3000, 2000, 100000, 40, 6),
+    (20000, 10000, 2000000, 32, 10), (20000, 10000, 2000000, 64, 6),
+    (5000, 4000, 400000, 128, 5), (60000, 30000, 6000000, 32, 8),
 ]
 
 
-@pytest.mark.parametrize("m,n,nnz,k,iters,tol", TRAIN_CASES)
-def test_training_rmse_matches_oracle(pkg, orc, m, n, nnz, k, iters, tol):
+@pytest.mark.parametrize("m,n,nnz,k,iters", TRAIN_CASES)
+def test_training_rmse_matches_oracle(pkg, orc, m, n, nnz, k, iters, tol=RMSE_RTOL):
     R = pkg.synth_host(3, 0, nnz, m, n)
     t = pkg.Trainer(R, m, n, k=k); t.init_model(); t.train(iters)
     arr = t.export(); g_int = t.rmse(); t.close()
@@ -148,7 +155,7 @@ def test_edge_cases(pkg, orc):
     for k in (5, 12, 100):
         t = pkg.Trainer(R, 1200, 900, k=k); t.init_model(); t.train(4); arr = t.export(); t.close()
         want = orc.rmse(R, orc.train(R, 1200, 900, k=k, iters=4))
-        assert len(arr) == 5 + 2100 * k and abs(orc.rmse(R, arr) - want) / want < 0.03
+        assert len(arr) == 5 + 2100 * k and abs(orc.rmse(R, arr) - want) / want < RMSE_RTOL
 
 
 def test_determinism_of_everything_but_the_race(pkg):
@@ -180,7 +187,11 @@ def test_full_size_properties(pkg):
     assert (PG >= 1).all() and (QG >= 1).all()           # accumulators only grow (sums of squares)
     assert (P0[:, 8:] == P[:, 8:]).mean() < 0.01          # all k factors move after epoch 0
     rm = t.rmse()
-    assert 0.80 < rm < 0.87, rm                          # the oracle reaches 0.8363 after 12 epochs on these triples
+    want = FULL["c1"]["rmse_after"]["12"]                # the oracle on these exact triples (tests/golden/make_full_size.py)
+    assert abs(rm - want) / want < RMSE_RTOL, (rm, want)
+    # ... and within one epoch of the oracle's own trajectory (online error of every epoch)
+    otr = FULL["c1"]["tr_rmse"]
+    assert all(otr[i + 1] * (1 - 0.01) < tr[i] < otr[i - 1] * (1 + 0.01) for i in range(1, 11)), (tr, otr)
     arr = t.export()
     assert abs(pkg.rmse_array(arr, R) - rm) / rm < 1e-4  # export (scale, shrink, un-permute) is consistent
     t.close()
@@ -230,28 +241,92 @@ def test_stripe_rotation_one_rank_is_plain_sgd(pkg, orc, world):
     t.close()
     os.environ.pop("MFX_HOT_LEN")
     want = orc.rmse(R, orc.train(R, m, n, k=k, iters=iters))
-    # Sweeping the item stripes one after the other is a different (block-cyclic) order of the same updates and
-    # fits the training set a little faster than the reference's order: observed -1.5 % (2 stripes) and -3.0 %
-    # (4 stripes) after 8 epochs.  Not worse than the parity band, not implausibly better.
-    assert -0.06 < (got - want) / want < 0.03, (got, want)
+    # Sweeping the item slots one after the other is a different (block-cyclic) order of the same updates.
+    assert abs(got - want) / want < RMSE_RTOL, (got, want)
 
 
-def test_config2_full_size(pkg):
-    """BASELINE configs[2]: 1M x 500k, 100M ratings, k=64 (model 384 MB, beyond the L2s).  The oracle needs
-    260 s for 8 epochs of this; its result on these exact triples (seed 1) is recorded here:
-    RMSE 0.94767, tr_rmse per epoch 1.2245 1.0561 1.0375 1.0178 1.0004 0.9862 0.9752 0.9651."""
-    m, n, nnz, k = 1000000, 500000, 100000000, 64
-    R = pkg.synth_host(1, 0, nnz, m, n)
-    t = pkg.Trainer(R, m, n, k=k); t.init_model()
-    del R
+@pytest.mark.parametrize("epochs", [8, 12])
+def test_config2_full_size(pkg, epochs):
+    """BASELINE configs[2]: 1M x 500k, 100M ratings, k=64 (model 384 MB, beyond the L2s), the bench workload.  The
+    oracle needs minutes for this; its results on these exact triples are fixtures (tests/golden/full_size.json,
+    made by tests/golden/make_full_size.py)."""
+    import torch
+    g = FULL["c2"]
+    m, n, nnz, k = g["m"], g["n"], g["nnz"], g["k"]
+    R = torch.empty(nnz * 3, dtype=torch.int32, device="cuda")
+    pkg.synth_device(g["seed"], 0, nnz, m, n, R.data_ptr(), None, shard=0)
+    torch.cuda.synchronize()
+    t = pkg.Trainer(None, m, n, opts=pkg.default_options(k=k), device_ptr=R.data_ptr(), nnz=nnz); t.init_model()
     tr = []
-    for it in range(8):
+    for it in range(epochs):
         t.epoch(slow_only=(it == 0)); tr.append(np.sqrt(t.last_loss() / nnz) * t.info.scale)
     rm = t.rmse()
     t.close()
+    want = g["rmse_after"][str(epochs)]
     assert (np.diff(tr) < 0).all()
-    assert abs(tr[0] - 1.2245) / 1.2245 < 0.01          # epoch 0 starts from the same factors
-    assert abs(rm - 0.94767) / 0.94767 < 0.03, rm        # observed 0.925-0.928: the GPU path is slightly ahead
+    assert abs(tr[0] - g["tr_rmse"][0]) / g["tr_rmse"][0] < 0.01  # epoch 0 starts from the same factors
+    assert abs(rm - want) / want < RMSE_RTOL, (rm, want)
+    otr = g["tr_rmse"]                                           # within one epoch of the oracle's trajectory
+    assert all(otr[i + 1] * (1 - 0.01) < tr[i] < otr[i - 1] * (1 + 0.01) for i in range(1, min(epochs, 11))), (tr, otr)
+
+
+def test_gpu_follows_the_plan_order_emulation(pkg, orc):
+    """What is left between the GPU and the oracle's arithmetic walked in the GPU PLAN's own order on one CPU thread
+    (oracle/plan_order.c: same rounds, same lists side by side, same private owner copies, same hot-chain fold) is the
+    lock-free execution alone: 2 % on the final RMSE, and the same online error epoch by epoch."""
+    m, n, nnz, k, iters = 60000, 30000, 6000000, 32, 8
+    R = pkg.synth_host(3, 0, nnz, m, n)
+    hp = pkg.HostPlan(R, m, n, k=k)
+    want_arr, want_tr = orc.plan_order_train(hp, iters, chain_mode=orc.CHAIN_FOLD)
+    t = pkg.Trainer(R, m, n, k=k); t.init_model()
+    e, ts, sp = t.plan_copy()
+    assert np.array_equal(e, hp.entries) and np.array_equal(ts, hp.tasks)  # the emulation walks the very same plan
+    tr = []
+    for it in range(iters):
+        t.epoch(slow_only=(it == 0)); tr.append(np.sqrt(t.last_loss() / nnz) * t.info.scale)
+    got = orc.rmse(R, t.export()); t.close()
+    want = orc.rmse(R, want_arr)
+    assert abs(got - want) / want < 0.02, (got, want)
+    np.testing.assert_allclose(tr, want_tr, rtol=0.02)
+
+
+def test_head_rows_keep_their_updates(pkg, orc):
+    """Data with a 5 % head user and a 7 % head item (what the synthetic generator of the bench produces).  A heavy
+    owner row is cut into chains that run side by side; round 1 let the last chain overwrite the others, so such a
+    row kept a fraction of its updates and of its Adagrad growth.  Now: the head rows' accumulators match what the
+    plan-order emulation (no lost update by construction) accumulates, and their per-row error stays near the oracle's."""
+    m, n, nnz, k, iters = 20000, 10000, 2000000, 32, 12
+    R = pkg.synth_host(1, 0, nnz, m, n)
+    cu, cv = np.bincount(R["u"], minlength=m), np.bincount(R["v"], minlength=n)
+    hu, hv = int(cu.argmax()), int(cv.argmax())
+    assert cu[hu] > 0.05 * nnz and cv[hv] > 0.05 * nnz
+    want = orc.train(R, m, n, k=k, iters=iters)
+    t = pkg.Trainer(R, m, n, k=k); t.init_model(); t.train(iters)
+    arr = t.export(); P, Q, PG, QG = t.get_model(); pm, qm = t.maps(); info = t.info; t.close()
+    hp = pkg.HostPlan(R, m, n, k=k)
+    assert info.owner_is_q == 1 and hp.view.n_hot_slots > 0  # items are the owner side: the head item is cut into chains
+
+    def row_rmse(a, side, row):
+        Pm, Qm = a[5:5 + m * k].reshape(m, k), a[5 + m * k:].reshape(n, k)
+        sel = R[R[side] == row]
+        return float(np.sqrt(np.mean((sel["r"] - np.einsum("ij,ij->i", Pm[sel["u"]], Qm[sel["v"]])) ** 2)))
+
+    for side, row in (("u", hu), ("v", hv)):
+        got, ref = row_rmse(arr, side, row), row_rmse(want, side, row)
+        assert abs(got - ref) / ref < 0.10, (side, got, ref)  # observed -5 .. +2 % (a row's own error is a noisy figure)
+    # accumulator growth of the head item: the emulation loses nothing by construction
+    import ctypes as C
+    Pe, Qe = hp.init_factors()
+    PGe, QGe = np.ones((m, 2), dtype=np.float32), np.ones((n, 2), dtype=np.float32)
+    v = hp.view
+    ent, tsk, sp = (np.ascontiguousarray(x) for x in (hp.entries, hp.tasks, hp.slot_task_ptr))
+    sc = np.float32(v.scale)
+    orc.lib().orc_plan_order_train(ent.ctypes.data, tsk.ctypes.data, sp.ctypes.data, v.stripes, v.ratings_per_wave, v.k_aligned,
+                                   v.owner_is_q, Pe.ctypes.data, Qe.ctypes.data, PGe.ctypes.data, QGe.ctypes.data, v.n_hot_slots,
+                                   np.float32(0.1) / sc, np.float32(0.1) / sc, 0.1, iters, 0, orc.CHAIN_FOLD, orc.RSQRT_EXACT,
+                                   orc.RK_AS_BUILT, None)
+    ghv = QG[qm[hv]]; ehv = QGe[hp.q_map[hv]]
+    assert np.all(ghv > 0.5 * ehv) and np.all(ghv < 2.0 * ehv), (ghv, ehv)  # last-writer-wins kept ~1/60 of it
 
 
 def test_triplets_to_device_matches_read_triplet(pkg):
@@ -386,5 +461,5 @@ def test_mf_my_train_text_round_trip(pkg, orc, tmp_path):
     arr = np.concatenate([[0, m, n, 8, float(hdr["b"])], P.ravel(), Q.ravel()]).astype(np.float32)
     want = orc.rmse(R, orc.train(R, m, n, k=8, iters=40))
     got = orc.rmse(R, arr)
-    assert abs(got - want) / want < 0.03, (got, want)  # the text format keeps 6 significant digits
+    assert abs(got - want) / want < RMSE_RTOL, (got, want)  # (the text format keeps 6 significant digits)
     assert getattr(pkg.lib(), pkg.MANGLED["mf_my_train"])(b"/nonexistent/file", str(dst).encode()) == -1
