@@ -153,10 +153,16 @@ def test_stripe_count_is_pinned_per_job():
     pkg = ge.import_package()
     o = pkg.default_options(k=32)
     m, n = 100000, 16667
-    lo, hi = pkg.stripes_for(o, 3050000, m, n), pkg.stripes_for(o, 3300000, m, n)
-    assert (lo, hi) == (4, 8)  # the two pieces of ADVICE's example would have chosen different grids
-    R = pkg.synth_host(1, 0, 3300000, m, n)
-    a = pkg.HostPlan(R[:3050000], m, n, opts=pkg.default_options(k=32, stripes=lo))
+    # find two piece sizes on either side of the small-problem threshold (8 stripes above it, 4 below)
+    sizes = [int(x) for x in np.linspace(1.0e6, 6.0e6, 101)]
+    st = [pkg.stripes_for(o, z, m, n) for z in sizes]
+    assert st[0] == 4 and st[-1] == 8
+    cut = st.index(8)
+    n_lo, n_hi = sizes[cut - 1], sizes[cut]
+    lo, hi = pkg.stripes_for(o, n_lo, m, n), pkg.stripes_for(o, n_hi, m, n)
+    assert (lo, hi) == (4, 8)  # two pieces of one job, 5 % apart in size, would have chosen different grids
+    R = pkg.synth_host(1, 0, n_hi, m, n)
+    a = pkg.HostPlan(R[:n_lo], m, n, opts=pkg.default_options(k=32, stripes=lo))
     b = pkg.HostPlan(R, m, n, opts=pkg.default_options(k=32, stripes=lo))
     assert a.view.stripes == b.view.stripes == lo  # an explicit stripe count wins over the size heuristic
     o.stripes = 8
