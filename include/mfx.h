@@ -143,6 +143,13 @@ int mfx_trainer_plan_copy(mfx_trainer *t, void *entries, void *tasks, long long 
 int mfx_trainer_get_model(mfx_trainer *t, float *P, float *Q, float *PG, float *QG);
 int mfx_trainer_set_model(mfx_trainer *t, const float *P, const float *Q, const float *PG,
                           const float *QG);
+/* A raw model is expressed in the trainer's INTERNAL layout (id maps, stripe count, padded width): a checkpoint
+ * must carry the fingerprint of that layout and the number of epochs done (the first round of an epoch rotates
+ * with it), and a restoring trainer must compare before mfx_trainer_set_model (the Python binding's
+ * Trainer.checkpoint / Trainer.restore do). */
+int mfx_trainer_layout_fingerprint(mfx_trainer *t, unsigned long long *fp);
+long long mfx_trainer_epochs_done(mfx_trainer *t);
+int mfx_trainer_set_epochs_done(mfx_trainer *t, long long epochs);
 
 /* HIP-event timing of the epoch launches (events on the launch stream).  After
  * mfx_trainer_sync: number of launches timed since enable and their summed duration. */
@@ -196,6 +203,11 @@ void mfx_hostplan_destroy(mfx_hostplan *h);
  * mfx_trainer_create_device; release it with mfx_device_free. */
 int mfx_triplets_to_device(const float *triplets, long long count, int device, void **d_nodes, int *m, int *n);
 void mfx_device_free(void *p);
+
+/* Self-test of the memory behaviour the lock-free side of the kernel relies on: a row stored by one CU is seen by the
+ * non-temporal loads of another CU of the same XCD (kernels.hip: visibility_probe).  result5 = {rounds completed,
+ * stale rows seen, polls that ran out, CU of the writer, CU of the reader}; a healthy device gives {rounds, 0, 0, a, b}. */
+int mfx_selftest_visibility(int rounds, int *result5);
 
 /* Deterministic synthetic ratings: integer-only generator, identical on
  * host and device.  Writes ratings [first, first+count) of shard `shard` of problem `seed`:

@@ -28,7 +28,7 @@
  *   - glibc srand()/rand() (TYPE_3 additive feedback generator, degree 31,
  *       separation 3, 310 warm-up draws).
  *
- * Parity pinning: tests/test_oracle_vs_reference.py checks this file bit for
+ * Parity pinning: tests/test_oracle.py (test_live_reference_bit_exact) checks this file bit for
  * bit against the reference itself, compiled from /root/reference by
  * oracle/Makefile into oracle/_ref/libmf_ref.so and run with one worker
  * thread (quiet=true), and against the committed fixtures under

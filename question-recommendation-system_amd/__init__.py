@@ -104,6 +104,10 @@ def lib():
     L.mfx_trainer_get_model.argtypes = [vp, vp, vp, vp, vp]
     L.mfx_trainer_plan_copy.argtypes = [vp, vp, vp, vp]
     L.mfx_trainer_set_model.argtypes = [vp, vp, vp, vp, vp]
+    L.mfx_trainer_layout_fingerprint.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+    L.mfx_trainer_epochs_done.argtypes = [vp]
+    L.mfx_trainer_epochs_done.restype = ll
+    L.mfx_trainer_set_epochs_done.argtypes = [vp, ll]
     L.mfx_trainer_timing_enable.argtypes = [vp, i32]
     L.mfx_trainer_timing_read.argtypes = [vp, C.POINTER(ll), C.POINTER(C.c_double)]
     L.mfx_trainer_export.argtypes = [vp, vp, ll]
@@ -252,6 +256,14 @@ def triplets_to_device(triplets, device=-1):
     return p.value, m.value, n.value
 
 
+def selftest_visibility(rounds=2000):
+    """(rounds completed, stale rows, polls that ran out, writer CU, reader CU) of mfx_selftest_visibility."""
+    out = (C.c_int * 5)()
+    lib().mfx_selftest_visibility.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    _check(lib().mfx_selftest_visibility(rounds, out))
+    return tuple(out)
+
+
 def device_free(ptr):
     lib().mfx_device_free(ptr)
 
@@ -374,6 +386,24 @@ class Trainer:
         arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (P, Q, PG, QG)]
         _check(lib().mfx_trainer_set_model(self._h, *[a.ctypes.data for a in arrs]))
         self.info = self._info()
+
+    def layout_fingerprint(self):
+        v = C.c_ulonglong()
+        _check(lib().mfx_trainer_layout_fingerprint(self._h, C.byref(v)))
+        return v.value
+
+    def checkpoint(self):
+        """Training state: raw factors and accumulators in the internal layout, the layout's fingerprint, epochs done."""
+        P, Q, PG, QG = self.get_model()
+        return dict(P=P, Q=Q, PG=PG, QG=QG, fingerprint=self.layout_fingerprint(),
+                    epochs_done=lib().mfx_trainer_epochs_done(self._h))
+
+    def restore(self, ckpt):
+        """Refuses a state saved under another layout (other data, stripe count, id layout or width)."""
+        if int(ckpt["fingerprint"]) != self.layout_fingerprint():
+            raise MfxError("checkpoint was written under another internal layout (data, stripes, id layout or k differ)")
+        self.set_model(ckpt["P"], ckpt["Q"], ckpt["PG"], ckpt["QG"])
+        _check(lib().mfx_trainer_set_epochs_done(self._h, int(ckpt["epochs_done"])))
 
     def timing_enable(self, on=True):
         _check(lib().mfx_trainer_timing_enable(self._h, 1 if on else 0))

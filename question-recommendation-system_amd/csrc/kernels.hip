@@ -589,6 +589,54 @@ __global__ __launch_bounds__(256) void fold_hot_rows(float *rows, float *acc, fl
     for (int i = lane; i < HOT_SUB * stride; i += 64) s0[i] = 0.0f;
 }
 
+// Self-test of what the lock-free gathered side relies on: inside one XCD, a row stored by one CU (plain store,
+// write-through to the XCD's L2) is seen by the non-temporal loads (global nt and raw buffer aux = 2, the two forms
+// sgd_round uses) of ANOTHER CU -- they must not be served from that CU's own, stale L1 line.  The first two
+// workgroups that arrive on XCC 0 play ping-pong: A writes a row and raises a flag, B polls the flag with nt loads,
+// reads the row with both load forms, answers; every wait is bounded, nothing can hang.
+// out: [0] rounds completed, [1] stale rows seen, [2] polls that ran out, [3] CU of A, [4] CU of B
+__global__ __launch_bounds__(64) void visibility_probe(int *ticket, float *row, int *flag, int *ack, int rounds, int *out)
+{
+    if ((xcc_id() & 15) != 0) return;
+    __shared__ int role_s;
+    if (threadIdx.x == 0) role_s = atomicAdd(ticket, 1);
+    __syncthreads();
+    const int role = role_s;
+    if (role > 1) return;
+    const int lane = threadIdx.x;
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    if (lane == 0) out[3 + role] = (int)((hw >> 8) & 0xF) | (int)(((hw >> 13) & 0x7) << 4); // CU id | SE id << 4
+    const int SPIN = 400000;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(row, 64u * 4u);
+    int stale = 0, lost = 0, done = 0;
+    for (int i = 1; i <= rounds; ++i) {
+        if (role == 0) {
+            row[lane] = (float)i;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) *flag = i;
+            int spins = 0;
+            while (__builtin_nontemporal_load(ack) != i && ++spins < SPIN) asm volatile("" ::: "memory"); // (reload every time)
+            if (spins >= SPIN) { ++lost; break; }
+        } else {
+            int spins = 0;
+            while (__builtin_nontemporal_load(flag) != i && ++spins < SPIN) asm volatile("" ::: "memory");
+            if (spins >= SPIN) { ++lost; break; }
+            const float a = __builtin_nontemporal_load(row + lane);
+            const float b = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, 0, BUF_NT));
+            if (a != (float)i || b != (float)i) ++stale;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) *ack = i;
+        }
+        ++done;
+    }
+    for (int off = 32; off > 0; off >>= 1) stale += __shfl_down(stale, off);
+    if (lane == 0) {
+        if (role == 1) { out[0] = done; atomicAdd(&out[1], stale); }
+        atomicAdd(&out[2], lost);
+    }
+}
+
 // Which XCC ids does a grid land on?  One bit per id seen (run once per trainer).
 __global__ void probe_xcc(unsigned *mask)
 {
@@ -804,6 +852,12 @@ hipError_t launch_fold_hot(float *rows, float *acc, float *hot_acc, const int *h
     if (n_slots <= 0) return hipSuccess;
     hipLaunchKernelGGL(fold_hot_rows, dim3((n_slots + 3) / 4), dim3(256), 0, s, rows, acc, hot_acc, hot_row, n_slots, ka,
                        eta, rk1, slow_only, fold_mode, s_gain);
+    return hipGetLastError();
+}
+
+hipError_t launch_visibility_probe(int *ticket, float *row, int *flag, int *ack, int rounds, int *out, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(visibility_probe, dim3(grid), dim3(64), 0, s, ticket, row, flag, ack, rounds, out);
     return hipGetLastError();
 }
 

@@ -46,6 +46,7 @@ struct RoundArgs {
 hipError_t launch_sgd_round(int lanes, const RoundArgs &a, int grid, hipStream_t s);
 hipError_t launch_fold_hot(float *rows, float *acc, float *hot_acc, const int *hot_row, int n_slots, int ka, float eta,
                            float rk1, int slow_only, int fold_mode, float s_gain, hipStream_t s);
+hipError_t launch_visibility_probe(int *ticket, float *row, int *flag, int *ack, int rounds, int *out, int grid, hipStream_t s);
 hipError_t launch_probe_xcc(unsigned *mask, int grid, hipStream_t s);
 hipError_t launch_sq_err_entries(int lanes, const float *own_rows, const float *gat_rows,
                                  const EntryD *entries, long long n_entries, int ka, double *out,

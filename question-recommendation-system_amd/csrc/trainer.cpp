@@ -111,6 +111,7 @@ struct mfx_trainer {
     long long epochs_done = 0;
     double last_loss = 0;
     bool loss_pending = false;
+    bool cursors_live = false; // an epoch has run in THIS trainer since the cursors were last zeroed
 
     bool timing = false;
     long long timed_launches = 0;
@@ -216,7 +217,8 @@ static mfx::PlanConfig plan_config(const mfx_options &opt, int stripes, int wgs_
     cfg.lanes = mfx::lanes_for(mfx::k_aligned(opt.k));
     cfg.task_steps = opt.task_steps > 0 ? opt.task_steps : env_int("MFX_TASK_STEPS", 0);
     cfg.owner_side = opt.owner_side;
-    cfg.map_mode = env_int("MFX_MAP_MODE", opt.identity_maps); // 0 mass-balanced stripes, 1 identity, 2 the reference's shuffle
+    // 0 mass-balanced stripes, 1 identity, 2 the reference's shuffle; an explicit option wins over the experiment knob
+    cfg.map_mode = opt.identity_maps != 0 ? opt.identity_maps : env_int("MFX_MAP_MODE", 0);
     cfg.use_stats = opt.use_stats != 0;
     cfg.stats_avg = opt.stats_avg;
     cfg.stats_std = opt.stats_std;
@@ -554,7 +556,7 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
     if (part == 0) {
         // one launch checks the cursors of the epoch before (sticky flag, read by verify_rounds) and zeroes
         // the loss sums and the task cursors
-        HIP_TRY(mfx::launch_epoch_reset(t->dLossP, t->dSlotStateP, t->dSlotPtr.p, ns * ns, t->epochs_done > 0 ? 1 : 0,
+        HIP_TRY(mfx::launch_epoch_reset(t->dLossP, t->dSlotStateP, t->dSlotPtr.p, ns * ns, t->cursors_live ? 1 : 0,
                                         t->dSticky.p, s));
     }
 
@@ -664,6 +666,7 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
     if (part == nparts - 1) {
         t->epochs_done++;
         t->loss_pending = true;
+        t->cursors_live = true;
     }
     return MFX_OK;
 }
@@ -834,6 +837,35 @@ int mfx_trainer_set_model(mfx_trainer *t, const float *P, const float *Q, const 
     if (PG) HIP_TRY(hipMemcpy(t->dPG, PG, (size_t)p.m * 8, hipMemcpyHostToDevice));
     if (QG) HIP_TRY(hipMemcpy(t->dQG, QG, (size_t)p.n * 8, hipMemcpyHostToDevice));
     t->model_ready = true;
+    return MFX_OK;
+}
+
+// Fingerprint of the internal layout a raw model (mfx_trainer_get_model) is expressed in: sizes, padded width,
+// stripe count, owner side and both id maps.  A checkpoint carries it; a trainer built with another stripe count,
+// id layout or data refuses the state instead of training on rows that mean something else.
+int mfx_trainer_layout_fingerprint(mfx_trainer *t, unsigned long long *fp)
+{
+    if (!t || !fp) return fail(MFX_E_ARG, "null pointer");
+    const mfx::Plan &p = t->plan;
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&](unsigned long long v) { h = (h ^ v) * 1099511628211ull; };
+    mix((unsigned long long)p.m);
+    mix((unsigned long long)p.n);
+    mix((unsigned long long)p.ka);
+    mix((unsigned long long)p.ns);
+    mix(p.owner_is_q ? 1ull : 0ull);
+    for (int v : p.p_map) mix((unsigned long long)(unsigned)v);
+    for (int v : p.q_map) mix((unsigned long long)(unsigned)v);
+    *fp = h;
+    return MFX_OK;
+}
+
+long long mfx_trainer_epochs_done(mfx_trainer *t) { return t ? t->epochs_done : -1; }
+
+int mfx_trainer_set_epochs_done(mfx_trainer *t, long long epochs)
+{
+    if (!t || epochs < 0) return fail(MFX_E_ARG, "bad argument");
+    t->epochs_done = epochs; // the first round of an epoch rotates with this count (mfx_trainer_epoch_part)
     return MFX_OK;
 }
 
@@ -1204,6 +1236,29 @@ int mfx_triplets_to_device(const float *triplets, long long count, int device, v
     *d_nodes = nodes;
     *m = mn[0];
     *n = mn[1];
+    return MFX_OK;
+}
+
+int mfx_selftest_visibility(int rounds, int *result5)
+{
+    if (rounds < 1 || !result5) return fail(MFX_E_ARG, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(MFX_E_HIP, "no HIP device: the MI355X path cannot run (there is no CPU fallback)");
+    hipDeviceProp_t prop;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    DevBuf<int> words; // ticket, flag, ack (each on a line of its own), out[5]
+    DevBuf<float> row;
+    HIP_TRY(words.alloc(32 * 4));
+    HIP_TRY(row.alloc(64));
+    HIP_TRY(hipMemset(words.p, 0, 32 * 4 * sizeof(int)));
+    HIP_TRY(hipMemset(row.p, 0, 64 * sizeof(float)));
+    HIP_TRY(mfx::launch_visibility_probe(words.p, row.p, words.p + 32, words.p + 64, rounds, words.p + 96,
+                                         prop.multiProcessorCount, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(result5, words.p + 96, 5 * sizeof(int), hipMemcpyDeviceToHost));
     return MFX_OK;
 }
 

@@ -138,3 +138,11 @@ def test_predict_model_stays_resident(pkg, orc, small):
     po = np.stack([rng.integers(0, mo, 100), rng.integers(0, no, 100)], 1).astype(np.float32)
     np.testing.assert_allclose(pkg.predict_array(other, po), orc.predict(other, po), rtol=1e-5, atol=1e-6)
     pkg.predict_cache_drop()
+
+
+def test_stores_of_one_cu_reach_the_nt_loads_of_another(pkg):
+    """What the lock-free gathered side relies on (kernels.hip, "factor loads bypass the per-CU L1"): inside an XCD a row
+    stored by one CU is seen by the non-temporal loads -- global and raw-buffer form -- of another CU, never a stale L1 line."""
+    done, stale, lost, cu_a, cu_b = pkg.selftest_visibility(3000)
+    assert (done, stale, lost) == (3000, 0, 0), (done, stale, lost, cu_a, cu_b)
+    assert cu_a != cu_b  # the two workgroups really sat on different CUs

@@ -429,14 +429,25 @@ def test_checkpoint_resume(pkg):
     R = pkg.synth_host(21, 0, nnz, m, n)
     a = pkg.Trainer(R, m, n, k=k); a.init_model(); a.train(10); full = a.rmse(); a.close()
     b = pkg.Trainer(R, m, n, k=k); b.init_model(); b.train(5)
-    state = b.get_model(); b.close()
-    c = pkg.Trainer(R, m, n, k=k); c.set_model(*state)
+    ck = b.checkpoint(); b.close()
+    assert ck["epochs_done"] == 5
+    c = pkg.Trainer(R, m, n, k=k); c.restore(ck)
     for _ in range(5):
         c.epoch(slow_only=False)
     c.sync(); resumed = c.rmse()
     P, Q, PG, QG = c.get_model(); c.close()
     assert abs(resumed - full) / full < RMSE_RTOL
-    assert (PG >= state[2]).all() and (QG >= state[3]).all()  # accumulators carried on, not reset
+    assert (PG >= ck["PG"]).all() and (QG >= ck["QG"]).all()  # accumulators carried on, not reset
+    # a trainer with another internal layout refuses the state (it would train on rows that mean something else)
+    for other in (dict(k=k, stripes=4), dict(k=k, identity_maps=2)):
+        d = pkg.Trainer(R, m, n, **other)
+        with pytest.raises(pkg.MfxError, match="another internal layout"):
+            d.restore(ck)
+        d.close()
+    d = pkg.Trainer(R[: nnz // 2], m, n, k=k)
+    with pytest.raises(pkg.MfxError, match="another internal layout"):
+        d.restore(ck)
+    d.close()
 
 
 def test_mf_my_train_text_round_trip(pkg, orc, tmp_path):
