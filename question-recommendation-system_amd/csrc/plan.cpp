@@ -284,6 +284,7 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
         p.n_padding += o.padding;
     }
     p.headers.clear();
+    p.round_hot.assign((size_t)NS, 0);
     p.tasks.clear();
     p.tasks.reserve(tot_t);
     places.clear();
@@ -301,6 +302,7 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
                 pl.dst += ebase;
                 places.push_back(pl);
             }
+            if (!o.headers.empty()) p.round_hot[r] = 1;
             for (HeaderRec h : o.headers) {
                 h.dst += ebase;
                 p.headers.push_back(h);

@@ -84,6 +84,7 @@ struct Plan {
     std::vector<HeaderRec> headers;       // hot-chain header entries (already part of `entries` on the host path)
     long long n_hot_slots = 0;            // distinct rows that are cut into chains somewhere
     std::vector<int> hot_rows;            // combine slot -> internal owner row
+    std::vector<char> round_hot;          // ns flags: does round r hold any chain (is there anything to fold behind it)?
     long long n_entries = 0;   // entries.size() on the host path; on the device path the array lives in HBM only
     long long n_hot_rows = 0;
     long long n_padding = 0;

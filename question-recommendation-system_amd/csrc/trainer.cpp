@@ -655,6 +655,7 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
         a.slot_cursor = t->dSlotStateP + (size_t)r * ns;
         HIP_TRY(mfx::launch_sgd_round(p.lanes, a, grid, s));
         // the chains of the hot owner rows of this round are folded into their rows (kernels.hip: fold_hot_rows)
+        if (!p.round_hot.empty() && !p.round_hot[(size_t)r]) continue; // no chain in this round: nothing to fold
         HIP_TRY(mfx::launch_fold_hot(a.own_rows, a.own_acc, t->dHotAcc.p, t->dHotRow.p, (int)p.n_hot_slots, p.ka, a.eta,
                                      a.rk1, a.slow_only, env_int("MFX_FOLD_MODE", 0),
                                      (float)env_int("MFX_HOT_S_GAIN", (int)mfx::HOT_S_GAIN), s));
