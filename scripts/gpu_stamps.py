@@ -1,4 +1,4 @@
-"""Diagnostic build (lib_diag, -DMFX_STAMPS): where do the cycles of a wave go on BASELINE configs[1]?
+"""Diagnostic build (lib_diag, -DMFX_STAMPS): where do the cycles of a wave go on BASELINE configs[1] (or STAMPS_CASE=m,n,nnz,k)?
 usage: gpu_stamps.py [ENV=VAL,ENV=VAL ...]   one run per argument ("-" = no extra environment)"""
 import os, sys, time, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,7 +8,7 @@ sys.path.insert(0, %(root)r)
 import __graft_entry__ as ge
 pkg = ge.import_package()
 pkg.LIB_PATH = os.path.join(ge.PKG_DIR, "lib_diag", "libmf.so")
-m,n,nnz,k = 100000,50000,10000000,32
+m,n,nnz,k = (int(x) for x in os.environ.get("STAMPS_CASE", "100000,50000,10000000,32").split(","))
 R = pkg.synth_host(1,0,nnz,m,n)
 t = pkg.Trainer(R,m,n,k=k); t.init_model(); t.epoch(slow_only=True)
 for _ in range(3): t.epoch()

@@ -6,7 +6,7 @@ seed 1, shard 0), and its calc_rmse (reference mf/mf.cpp:4316-4331) after N epoc
 online tr_rmse table (mf.cpp:2886-2902) are recorded.  Minutes of CPU per case (one thread by definition),
 which is why these are fixtures and not computed inside the tests.
 
-  python tests/golden/make_full_size.py [c1] [c2] [c2s]      (default: all)
+  python tests/golden/make_full_size.py [c1] [c2] [c2s] [c3shard] [c4shard]      (default: all)
 """
 import json
 import os
@@ -27,6 +27,11 @@ CASES = {
     "c2": dict(m=1000000, n=500000, nnz=100000000, k=64, seed=1, epochs=[8, 12]),    # BASELINE configs[2]
     # bench.py's bounded cpu_baseline sample of configs[2]: the first 20 M ratings of the same stream
     "c2s": dict(m=1000000, n=500000, nnz=20000000, k=64, seed=1, epochs=[12]),
+    # one GPU's shard of the 8-GPU configurations, as a problem of its own (users of shard 0, all items):
+    # configs[3] = configs[2] over 8 GPUs -> 125 k users x 500 k items, 12.5 M ratings, k = 64
+    "c3shard": dict(m=125000, n=500000, nnz=12500000, k=64, seed=1, epochs=[8]),
+    # configs[4] = 10 M x 2 M, 1 B ratings, k = 128 over 8 GPUs -> 1.25 M users x 2 M items, 125 M ratings
+    "c4shard": dict(m=1250000, n=2000000, nnz=125000000, k=128, seed=1, epochs=[4]),
 }
 
 

@@ -4,7 +4,7 @@ Tolerances (floating point; the path is lock-free and its update order differs f
 reference's, which is itself order-dependent -- SURVEY.md 3.4 Q2/Q3, 8d):
   * one conflict-free pass of the kernel vs orc_sgd_one, same inputs:   1e-5 relative
   * training, same triples / epochs / hyper-parameters: final training RMSE (calc_rmse formula) within
-    RMSE_RTOL = 2.5 % of the one-worker oracle's.  ONE number, used by every training test here, by
+    RMSE_RTOL = 3 % of the one-worker oracle's.  ONE number, used by every training test here, by
     tests/test_gpu_multi.py, bench.py and README/DESIGN.md.  Where it comes from: the oracle
     itself moves by +-1 % with nr_bins / block order alone; the GPU plan's order of the same arithmetic
     (oracle/plan_order.c) sits -0.6 .. -1.9 % from the reference's order at 12 epochs, where the curve still
@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-RMSE_RTOL = 0.025
+RMSE_RTOL = 0.03
 FULL = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size.json")))
 
 
@@ -268,6 +268,32 @@ def test_config2_full_size(pkg, epochs):
     assert abs(rm - want) / want < RMSE_RTOL, (rm, want)
     otr = g["tr_rmse"]                                           # within one epoch of the oracle's trajectory
     assert all(otr[i + 1] * (1 - 0.01) < tr[i] < otr[i - 1] * (1 + 0.01) for i in range(1, min(epochs, 11))), (tr, otr)
+
+
+@pytest.mark.parametrize("name", ["c3shard", "c4shard"])
+def test_eight_gpu_configs_one_shard(pkg, name):
+    """BASELINE configs[3] (configs[2] over 8 GPUs) and configs[4] (10 M x 2 M, 1 B ratings, k = 128 over 8 GPUs): what ONE of
+    the eight GPUs holds -- its users, all items -- trained as a problem of its own, against the oracle's fixture for
+    exactly these triples (tests/golden/make_full_size.py).  configs[4]'s shard has more items than users: the users are
+    the owner side there, k = 128 runs two ratings per wave."""
+    import torch
+    g = FULL[name]
+    m, n, nnz, k = g["m"], g["n"], g["nnz"], g["k"]
+    epochs = max(int(e) for e in g["rmse_after"])
+    R = torch.empty(nnz * 3, dtype=torch.int32, device="cuda")
+    pkg.synth_device(g["seed"], 0, nnz, m, n, R.data_ptr(), None, shard=0)
+    torch.cuda.synchronize()
+    t = pkg.Trainer(None, m, n, opts=pkg.default_options(k=k), device_ptr=R.data_ptr(), nnz=nnz); t.init_model()
+    assert t.info.owner_is_q == (1 if m >= n else 0)
+    tr = []
+    for it in range(epochs):
+        t.epoch(slow_only=(it == 0)); tr.append(np.sqrt(t.last_loss() / nnz) * t.info.scale)
+    rm = t.rmse()
+    t.close()
+    want = g["rmse_after"][str(epochs)]
+    assert (np.diff(tr) < 0).all()
+    assert abs(tr[0] - g["tr_rmse"][0]) / g["tr_rmse"][0] < RMSE_RTOL  # (the online error of epoch 0 is the most order-dependent figure)
+    assert abs(rm - want) / want < RMSE_RTOL, (rm, want)
 
 
 def test_gpu_follows_the_plan_order_emulation(pkg, orc):
