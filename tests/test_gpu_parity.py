@@ -316,6 +316,36 @@ def test_gpu_follows_the_plan_order_emulation(pkg, orc):
     np.testing.assert_allclose(tr, want_tr, rtol=0.02)
 
 
+@pytest.mark.parametrize("k", [8, 40, 64])
+def test_hot_chain_fold_equals_the_emulation(pkg, orc, k):
+    """Eight items rated by 750 users each, every user exactly once: every visit is cut into chains, no gathered row is
+    touched twice, so nothing depends on timing -- the kernel's chains + fold_hot_rows must reproduce the plan-order
+    emulation's fold (same formula on the CPU) up to the order of the float sums."""
+    m, n = 6000, 8
+    rng = np.random.default_rng(k)
+    R = pkg.as_nodes(rng.permutation(m), np.arange(m) % n, rng.uniform(1, 5, m).astype(np.float32))
+    hp = pkg.HostPlan(R, m, n, k=k)
+    v = hp.view
+    assert v.owner_is_q == 1 and v.n_hot_slots == n and (hp.entries["gat"] < -1).sum() >= 2 * n
+    t = pkg.Trainer(R, m, n, k=k); t.init_model()
+    e, ts, sp = t.plan_copy()
+    assert np.array_equal(e, hp.entries)
+    Pe, Qe = hp.init_factors()
+    PGe, QGe = np.ones((m, 2), dtype=np.float32), np.ones((n, 2), dtype=np.float32)
+    ent, tsk, spp = (np.ascontiguousarray(x) for x in (hp.entries, hp.tasks, hp.slot_task_ptr))
+    sc = np.float32(v.scale)
+    loss = np.zeros(2)
+    orc.lib().orc_plan_order_train(ent.ctypes.data, tsk.ctypes.data, spp.ctypes.data, v.stripes, v.ratings_per_wave, v.k_aligned,
+                                   v.owner_is_q, Pe.ctypes.data, Qe.ctypes.data, PGe.ctypes.data, QGe.ctypes.data, v.n_hot_slots,
+                                   np.float32(0.1) / sc, np.float32(0.1) / sc, 0.1, 2, 0, orc.CHAIN_FOLD, orc.RSQRT_EXACT,
+                                   orc.RK_AS_BUILT, loss.ctypes.data)
+    t.epoch(slow_only=True); l0 = t.last_loss(); t.epoch(); l1 = t.last_loss(); t.sync()
+    P, Q, PG, QG = t.get_model(); t.close()
+    np.testing.assert_allclose([l0, l1], loss, rtol=1e-4)
+    for got, want in ((Q, Qe), (QG, QGe), (P, Pe), (PG, PGe)):
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5)
+
+
 def test_head_rows_keep_their_updates(pkg, orc):
     """Data with a 5 % head user and a 7 % head item (what the synthetic generator of the bench produces).  A heavy
     owner row is cut into chains that run side by side; round 1 let the last chain overwrite the others, so such a
