@@ -61,6 +61,7 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
     const double study_pow = getenv("ORC_STUDY_POW") ? atof(getenv("ORC_STUDY_POW")) : 0.0;
     const double study_reg = getenv("ORC_STUDY_REG") ? atof(getenv("ORC_STUDY_REG")) : 0.0;
     const int study_dump = getenv("ORC_STUDY_DUMP") ? atoi(getenv("ORC_STUDY_DUMP")) : 0;
+    const int study_dump_minn = getenv("ORC_STUDY_DUMP_MINN") ? atoi(getenv("ORC_STUDY_DUMP_MINN")) : 0;
     int dumped = 0;
     const double study_blend = getenv("ORC_STUDY_BLEND") ? atof(getenv("ORC_STUDY_BLEND")) : 0.0;
     const double study_smul = getenv("ORC_STUDY_SMUL") ? atof(getenv("ORC_STUDY_SMUL")) : 128.0; /* = HOT_S_GAIN of kernels.hpp */
@@ -202,7 +203,7 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
                                             const float Sseq = ts0 * (c0 + 8 * reg) + ts1 * (c1 + (ka - 8) * reg),
                                                         Sch = (tc0 * (c0 + 8 * reg) + tc1 * (c1 + (ka - 8) * reg)) * rn;
                                             const float phi = damp((float)study_smul * Sseq) / damp((float)study_smul * Sch);
-                                            if (study_dump && ep == study_dump && dumped < 400 && (dumped++ % 4) == 0)
+                                            if (study_dump && ep == study_dump && (L->hot_n & 0x7FFF) >= study_dump_minn && dumped < 4000 && (dumped++ % 4) == 0)
                                                 fprintf(stderr, "fold ep %d n %d N %.0f G0 %.1f %.1f A %.2f %.2f E %.1f Sseq %.3f Sch %.3f phi %.3f sc %.3f %.3f\n", ep,
                                                         L->hot_n & 0x7FFF, N, accp[0], accp[1], A0, A1, E, Sseq, Sch, phi, ts0 / tc0, ts1 / tc1);
                                             for (d = 0; d < ka; d++)
