@@ -248,8 +248,9 @@ def main():
     ap.add_argument("--combine", default=os.environ.get("MFX_COMBINE", "rotate"),
                     help="how the item factors Q are shared when N>1: rotate (item slots travel round the ring of "
                          "ranks, one writer per row: exact SGD) | avg (replicas averaged by all-reduce)")
-    ap.add_argument("--slots-per-rank", type=int, default=int(os.environ.get("MFX_SLOTS_PER_RANK", "2")),
-                    help="rotate: item slots per rank (2 = the ring transfer runs under the next step's kernels)")
+    ap.add_argument("--slots-per-rank", type=int, default=int(os.environ.get("MFX_SLOTS_PER_RANK", "0")),
+                    help="rotate: item slots per rank (2 = the ring transfer runs under the next step's kernels, 1 = fewer "
+                         "passes over the user factors, transfer exposed; 0 = auto: 2 up to 4 GPUs, 1 beyond)")
     ap.add_argument("--syncs-per-epoch", type=int, default=int(os.environ.get("MFX_SYNCS_PER_EPOCH", "1")),
                     help="avg: RCCL averaging points per epoch when N>1 (1..stripes)")
     args = ap.parse_args()
@@ -443,7 +444,7 @@ def main():
                                                                                  "rotate round the ranks" if rotate else "averaged"),
                        "m_per_gpu": m, "n": n, "nnz_per_gpu": nnz, "k": k, "lambda": HYPER["lambda_p"], "eta": HYPER["eta"],
                        "stripes": info.stripes, "combine": args.combine, "exchanges_per_epoch": nsync,
-                       "slots_per_rank": args.slots_per_rank if rotate else None},
+                       "slots_per_rank": t.c if rotate else None},
             "final_rmse": rmse, "epochs_trained": 1 + args.warmup + args.steps, "rounds_verified": True,
             "roofline": roofline_block("n%d" % world, info, nnz, args.steps, launches, launch_s, note),
         }

@@ -7,9 +7,10 @@ factors Q over RCCL (torch.distributed backend "nccl" on ROCm; "gloo" in the CPU
           trained at step t is passed to rank r-1, which needs it at step t + c (point-to-point
           over xGMI).  Every row has one writer at any time, so the result is ordinary SGD -- the
           reference scheduler's rule (no two live blocks share a stripe, reference
-          mf/mf.cpp:133-141) carried across GPUs.  With c = 2 (default) the transfer of the slot
-          trained at step t-1 runs under the kernels of step t (double buffering); c = 1 is the
-          plain "train, then shift" ring.
+          mf/mf.cpp:133-141) carried across GPUs.  With c = 2 (default up to 4 ranks) the transfer of
+          the slot trained at step t-1 runs under the kernels of step t (double buffering); c = 1
+          (default beyond 4 ranks: fewer, larger slot trainers) is the plain "train, then shift" ring
+          (auto_slots_per_rank).
   avg     -- Q replicated, all-reduce mean after each (part of an) epoch, as BASELINE.json words it.
           Measured to lose the fit (4 ranks, 20 epochs: RMSE 0.97 vs 0.72): the replicas' latent
           bases drift apart between averaging points.  Kept selectable for comparison.
@@ -179,6 +180,15 @@ class SlotRing:
                 self.view(s).copy_(parts[r][j * self.slot_elems:(j + 1) * self.slot_elems])
 
 
+def auto_slots_per_rank(world):
+    """Two slots per rank hide the ring transfer under the next step's kernels but double the number of passes over the
+    rank's user factors (S = c*N slot trainers, each sweeping all of P); one slot per rank leaves the transfer of Q -- one
+    full copy of Q per rank and epoch, whatever N -- exposed.  Measured compute of one rank on configs[2] per GPU (no
+    peers, profiles/experiments/r02_rotation_one_rank_compute.log), ms per epoch: c = 2: 11.4 / 13.4 / 18.0 at N = 2 / 4 / 8;
+    c = 1: 10.5 / 11.3 / 13.4, plus 132 MB of point-to-point traffic (1.3 .. 2.6 ms at 100 .. 50 GB/s per link).  Hence:"""
+    return 2 if world <= 4 else 1
+
+
 def _array_hash(a):
     """Order-sensitive 62-bit fingerprint of an int array (layout agreement checks)."""
     a = np.ascontiguousarray(a, dtype=np.int64)
@@ -193,12 +203,14 @@ class RotatingTrainer:
     R_local: this rank's ratings (user ids local to the rank, item ids global) as a numpy NODE array or an
     int32 torch tensor of 3*nnz elements on the device ((u, v, bits of r) triples, as mfx_synth_device writes)."""
 
-    def __init__(self, pkg, R_local, m, n, world, rank, dist, torch_device, backend="nccl", slots_per_rank=2,
+    def __init__(self, pkg, R_local, m, n, world, rank, dist, torch_device, backend="nccl", slots_per_rank=0,
                  **opt_kw):
         import torch
         dev = torch_device
         self.pkg, self.dist, self.world, self.rank, self.backend = pkg, dist, world, rank, backend
         live = dist is not None and world > 1
+        if not slots_per_rank:  # auto, see auto_slots_per_rank
+            slots_per_rank = auto_slots_per_rank(world)
         c = slots_per_rank if world > 1 else 1
         S = c * world
         self.c, self.S, self.m, self.n = c, S, m, n

@@ -10,6 +10,7 @@ pkg = ge.import_package()
 spec = importlib.util.spec_from_file_location("qrs_multi", os.path.join(ge.PKG_DIR, "multi.py"))
 multi = importlib.util.module_from_spec(spec); spec.loader.exec_module(multi)
 case = sys.argv[1] if len(sys.argv) > 1 else "c2"
+C = int(sys.argv[2]) if len(sys.argv) > 2 else 2  # slots per rank
 m, n, nnz, k = {"c1": (100000, 50000, 10000000, 32), "c2": (1000000, 500000, 100000000, 64)}[case]
 dev = torch.device("cuda", 0)
 torch.cuda.set_stream(torch.cuda.Stream(device=dev))
@@ -20,7 +21,7 @@ for N in (1, 2, 4, 8):
     pkg.synth_device(1, 0, nnz, m, n, R.data_ptr(), None, shard=0)
     torch.cuda.synchronize()
     t0 = time.time()
-    t = multi.RotatingTrainer(pkg, R, m, n, N, 0, None, dev, slots_per_rank=2, k=k)
+    t = multi.RotatingTrainer(pkg, R, m, n, N, 0, None, dev, slots_per_rank=C, k=k)
     del R
     build = time.time() - t0
     t.epoch(slow_only=True, stream=stream)
@@ -36,7 +37,7 @@ for N in (1, 2, 4, 8):
     t.sync()
     rm = t.rmse()
     base = base or ms
-    print(json.dumps(dict(case=case, ranks=N, slot_trainers=len(t.trainers), stripes=t.stripes, ms_per_epoch=ms, vs_one=ms / base,
+    print(json.dumps(dict(case=case, slots_per_rank=C, ranks=N, slot_trainers=len(t.trainers), stripes=t.stripes, ms_per_epoch=ms, vs_one=ms / base,
                           rmse_after_9_epochs=rm, build_s=build, launches_per_epoch=len(t.trainers) * t.stripes)), flush=True)
     t.close()
     del t
