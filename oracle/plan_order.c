@@ -15,6 +15,9 @@
  *   1  private copies, folded when the last chain of the launch ends (kernels.hip "hot chains", same formula)
  *   2  no private copies for chains: every chain updates the row in memory at once (what one thread walking the
  *      interleaved lists would do -- the sequential meaning of this order)
+ *   6  (study) private copies; chain number idx of a row starts with its accumulators advanced by idx x the growth one
+ *      chain of that row showed at the row's fold before (so the step sizes along the visit fall as they would
+ *      sequentially); summed change damped as in mode 1 without the step-size ratio
  *   3  private copies; every chain's change is weighted by what a sequential pass would have left of it -- the
  *      step-size ratio of its place in the visit and exp(-contraction of the chains behind it) -- and the weighted
  *      changes are summed
@@ -37,6 +40,7 @@ typedef struct {
     float e0;          /* list's squared-error sum when the chain began */
     float tsum;
     float og[2];
+    float goff[2];     /* chain_mode 6: accumulator advance this chain started with */
     float *o;          /* private copy of the owner row (ka floats) */
     int shared;        /* chain_mode 2: the visit works on the row in memory */
 } pl_list;
@@ -54,6 +58,7 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
     float *own_acc = owner_is_q ? QG : PG, *gat_acc = owner_is_q ? PG : QG;
     const float lam_own = owner_is_q ? lambda_q : lambda_p, lam_gat = owner_is_q ? lambda_p : lambda_q;
     const float rk1 = (rk_mode == ORC_RK_AS_BUILT || ka == 8) ? 0.125f : 1.0f / (float)(ka - 8);
+    float *hot_growth = (float *)calloc((size_t)(n_hot_slots > 0 ? n_hot_slots : 1) * 2, sizeof(float));
     float *hot_acc = (float *)calloc((size_t)(n_hot_slots > 0 ? n_hot_slots : 1) * (size_t)(ka + 4), sizeof(float));
     int *hot_done = (int *)calloc((size_t)(n_hot_slots > 0 ? n_hot_slots : 1), sizeof(int));
     long long max_tasks = 0;
@@ -64,7 +69,8 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
     const int study_dump_minn = getenv("ORC_STUDY_DUMP_MINN") ? atoi(getenv("ORC_STUDY_DUMP_MINN")) : 0;
     int dumped = 0;
     const double study_blend = getenv("ORC_STUDY_BLEND") ? atof(getenv("ORC_STUDY_BLEND")) : 0.0;
-    const double study_smul = getenv("ORC_STUDY_SMUL") ? atof(getenv("ORC_STUDY_SMUL")) : 128.0; /* = HOT_S_GAIN of kernels.hpp */
+    const double study_smul = getenv("ORC_STUDY_SMUL") ? atof(getenv("ORC_STUDY_SMUL")) : 8.0; /* = HOT_S_GAIN of kernels.hpp */
+    const double study_rgain = getenv("ORC_STUDY_RGAIN") ? atof(getenv("ORC_STUDY_RGAIN")) : 1.0;
     const int study_avg = getenv("ORC_STUDY_AVG") != NULL;
     const double study_gain = getenv("ORC_STUDY_GAIN") ? atof(getenv("ORC_STUDY_GAIN")) : 1.0;
     pl_list *lists;
@@ -126,7 +132,32 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
                                 if (L->cur != 0xFFFFFFFFu && !L->shared) { /* close_visit */
                                     float *rowp = own_rows + (size_t)L->cur * ka, *accp = own_acc + (size_t)L->cur * 2;
                                     int d;
-                                    if (L->hot_n != 0 && (chain_mode == 4 || chain_mode == 5)) {
+                                    if (L->hot_n != 0 && chain_mode == 6) {
+                                        float *slot = hot_acc + (size_t)(L->hot_h & 0xFFFFFu) * (ka + 4);
+                                        const int nch = L->hot_n & 0x7FFF;
+                                        for (d = 0; d < ka; d++)
+                                            slot[d] += L->o[d] - rowp[d];
+                                        slot[ka] += L->og[0] - accp[0] - L->goff[0];
+                                        slot[ka + 1] += L->og[1] - accp[1] - L->goff[1];
+                                        slot[ka + 2] += L->tsum - L->e0;
+                                        slot[ka + 3] += (float)(L->hot_h >> 20);
+                                        if (++hot_done[L->hot_h & 0xFFFFFu] == nch) {
+                                            const float A0 = slot[ka], A1 = slot[ka + 1], E = slot[ka + 2], N = slot[ka + 3];
+                                            const float ts0 = 1.0f / (sqrtf(accp[0] + A0) + sqrtf(accp[0])), ts1 = 1.0f / (sqrtf(accp[1] + A1) + sqrtf(accp[1]));
+                                            const float cq = E > 0.0f ? 2.0f * eta * N / E : 0.0f;
+                                            const float Sseq = ts0 * cq * A0 * 8.0f + ts1 * cq * A1 / rk1;
+                                            const float phi = damp((float)study_smul * Sseq) / damp((float)study_smul * Sseq / (float)nch);
+                                            float *gr = hot_growth + (size_t)(L->hot_h & 0xFFFFFu) * 2;
+                                            for (d = 0; d < ka; d++)
+                                                rowp[d] += phi * slot[d];
+                                            accp[0] += A0;
+                                            accp[1] += A1;
+                                            gr[0] = A0 / (float)nch;
+                                            gr[1] = A1 / (float)nch;
+                                            memset(slot, 0, sizeof(float) * (ka + 4));
+                                            hot_done[L->hot_h & 0xFFFFFu] = 0;
+                                        }
+                                    } else if (L->hot_n != 0 && (chain_mode == 4 || chain_mode == 5)) {
                                         /* 4: rows are folded as a plain damped sum (phi of mode 1 without the step-size ratio);
                                            5: only the accumulator growth is summed */
                                         float *slot = hot_acc + (size_t)(L->hot_h & 0xFFFFFu) * (ka + 4);
@@ -168,7 +199,7 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
                                                      (sqrtf(g0[j] + nch * Ac[j]) - sqrtf(g0[j] + (idx + 1) * Ac[j]));
                                         }
                                         for (d = 0; d < ka; d++)
-                                            slot[d] += w[d >= 8] * expf(-R) * (L->o[d] - rowp[d]);
+                                            slot[d] += w[d >= 8] * expf(-(float)study_rgain * R) * (L->o[d] - rowp[d]);
                                         slot[ka] += Ac[0];
                                         slot[ka + 1] += Ac[1];
                                         if (++hot_done[L->hot_h & 0xFFFFFu] == nch) {
@@ -228,6 +259,15 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
                                     memcpy(L->o, own_rows + (size_t)id * ka, sizeof(float) * ka);
                                     L->og[0] = own_acc[(size_t)id * 2];
                                     L->og[1] = own_acc[(size_t)id * 2 + 1];
+                                    L->goff[0] = L->goff[1] = 0.0f;
+                                    if (hdr && chain_mode == 6) {
+                                        const int idx = L->hot_n >> 16;
+                                        const float *gr = hot_growth + (size_t)(L->hot_h & 0xFFFFFu) * 2;
+                                        L->goff[0] = idx * gr[0];
+                                        L->goff[1] = idx * gr[1];
+                                        L->og[0] += L->goff[0];
+                                        L->og[1] += L->goff[1];
+                                    }
                                 }
                             }
                             if (act) {
@@ -252,6 +292,7 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
     }
     free(lists);
     free(copies);
+    free(hot_growth);
     free(hot_acc);
     free(hot_done);
     return 0;

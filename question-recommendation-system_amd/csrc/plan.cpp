@@ -94,6 +94,7 @@ void pack_class(const std::vector<Visit> &visits, size_t vbeg, size_t vend, int 
                 BlockPack &out, long long force_ntasks = 0)
 {
     if (vbeg >= vend) return;
+    static const int list_order = getenv("MFX_LIST_ORDER") ? atoi(getenv("MFX_LIST_ORDER")) : 1;
     // load of a visit in steps: its ratings, plus the header entry of a hot chain
     auto steps_of = [](const Visit &v) { return v.len + (v.nch ? 1u : 0u); };
     long long L = 0;
@@ -131,6 +132,21 @@ void pack_class(const std::vector<Visit> &visits, size_t vbeg, size_t vend, int 
         for (int g = 0; g < G; ++g) {
             uint32_t lst = order[t * G + g];
             uint32_t step = 0;
+            // Which visits a list holds comes from the longest-first packing above (equal loads); the ORDER they are
+            // run in does not matter for the load.  As packed (round 1) every launch did all its heavy rows first and
+            // all its light rows last -- a systematic order the reference does not have (it walks a block sorted by
+            // row id, mf.cpp:843-852), worth -0.6 % (20 M sample) to -1.9 % (configs[2]) of final RMSE by itself in the
+            // order emulation.  MFX_LIST_ORDER: 0 as packed, 1 by owner row id (default: the reference's own
+            // order inside a block; +0.9 % epoch time on configs[2]), 2 scattered by a hash (same fit, +3.3 % time).
+            if (list_order == 1)
+                std::sort(list_visits[lst].begin(), list_visits[lst].end(), [&](uint32_t a, uint32_t b) {
+                    return visits[a].own != visits[b].own ? visits[a].own < visits[b].own : visits[a].idx < visits[b].idx;
+                });
+            else if (list_order == 2)
+                std::sort(list_visits[lst].begin(), list_visits[lst].end(), [&](uint32_t a, uint32_t b) {
+                    const uint32_t ha = (visits[a].own * 2654435761u) ^ (visits[a].idx * 40503u), hb = (visits[b].own * 2654435761u) ^ (visits[b].idx * 40503u);
+                    return ha != hb ? ha < hb : a < b;
+                });
             for (uint32_t vi : list_visits[lst]) {
                 const Visit &v = visits[vi];
                 if (v.nch) { // hot chain: a header entry first
