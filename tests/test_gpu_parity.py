@@ -6,9 +6,9 @@ reference's, which is itself order-dependent -- SURVEY.md 3.4 Q2/Q3, 8d):
   * training, same triples / epochs / hyper-parameters: final training RMSE (calc_rmse formula) within
     RMSE_RTOL = 3 % of the one-worker oracle's.  ONE number, used by every training test here, by
     tests/test_gpu_multi.py, bench.py and README/DESIGN.md.  Where it comes from: the oracle
-    itself moves by +-1 % with nr_bins / block order alone; the GPU plan's order of the same arithmetic
-    (oracle/plan_order.c) sits -0.6 .. -1.9 % from the reference's order at 12 epochs, where the curve still
-    falls 2 % per epoch; the lock-free execution adds -1.3 .. +1.6 %.
+    itself moves by +-1 % with nr_bins / block order alone; the sequential meaning of the GPU plan's order
+    (oracle/plan_order.c) sits within +-0.7 % of the reference's; folding the chains of the heavy rows adds
+    -2.2 .. +1.2 % (private row copies are not a sequential pass), the lock-free execution -0.2 .. -1.7 %.
   * GPU vs the oracle's arithmetic walked in the GPU plan's own order (plan_order.c): 2 %
   * predictions / calc_rmse from the same model array:                   1e-5 relative
 """
