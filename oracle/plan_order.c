@@ -69,7 +69,7 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
     const int study_dump_minn = getenv("ORC_STUDY_DUMP_MINN") ? atoi(getenv("ORC_STUDY_DUMP_MINN")) : 0;
     int dumped = 0;
     const double study_blend = getenv("ORC_STUDY_BLEND") ? atof(getenv("ORC_STUDY_BLEND")) : 0.0;
-    const double study_smul = getenv("ORC_STUDY_SMUL") ? atof(getenv("ORC_STUDY_SMUL")) : 8.0; /* = HOT_S_GAIN of kernels.hpp */
+    const double study_smul = getenv("ORC_STUDY_SMUL") ? atof(getenv("ORC_STUDY_SMUL")) : 6.0; /* = HOT_S_GAIN of kernels.hpp */
     const double study_rgain = getenv("ORC_STUDY_RGAIN") ? atof(getenv("ORC_STUDY_RGAIN")) : 1.0;
     const int study_avg = getenv("ORC_STUDY_AVG") != NULL;
     const double study_gain = getenv("ORC_STUDY_GAIN") ? atof(getenv("ORC_STUDY_GAIN")) : 1.0;

@@ -252,8 +252,9 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                 int hot_n = 0;        // > 0: the visit in progress is one of hot_n chains of a hot row (this launch)
                 unsigned hot_h = 0;   //      with combine slot (bits 0..19) and this chain's length (bits 20..31)
                 float hot_e0 = 0.0f;  //      list's squared-error sum when the chain began
-                f4 o = zero4;
+                f4 o = zero4, o_start = zero4;
                 float og0 = 1.0f, og1 = 1.0f;
+                f2 og_start = {1.0f, 1.0f};
                 unsigned pf = NONE;   // owner row in flight for the next visit
                 f4 on = zero4;
                 f2 ogn = {1.0f, 1.0f};
@@ -318,9 +319,11 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                 // ---- hot chains ----
                 // An owner row with more ratings in the block than one list should hold is cut into chains
                 // (plan.cpp), each run on its own register copy of the row -- possibly at the same time in
-                // other waves.  A chain does not write the row: it adds its end state (row, the two accumulator
-                // slots, its squared errors, its length, 1) to the row's combine slot with fire-and-forget float
-                // atomics; fold_hot_rows, launched behind every round, folds the sums into the row (see there).
+                // other waves.  A chain does not write the row: it adds what it CHANGED (row, the two accumulator
+                // slots; end state minus the start state it keeps in registers -- sums of end states cancel
+                // catastrophically for a row of 30 000 chains), its squared errors, its length and 1 to the row's
+                // combine slot with fire-and-forget float atomics; fold_hot_rows, launched behind every round,
+                // folds the sums into the row (see there).
                 // (A slot is HOT_SUB partial sums: hundreds of chains of one row adding to the same words would
                 //  queue at one memory channel, ~12 ns per wave instruction -- 47 us for the head row of configs[1].)
                 auto close_visit = [&]() {
@@ -333,14 +336,14 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                                                      (size_t)(((blockIdx.x * 4 + (threadIdx.x >> 6)) * G + grp) & (HOT_SUB - 1))) *
                                                         (size_t)(ka + HOT_EXTRA);
                     if (lane_ok) {
-                        unsafeAtomicAdd(slot + d0 + 0, o.x);
-                        unsafeAtomicAdd(slot + d0 + 1, o.y);
-                        unsafeAtomicAdd(slot + d0 + 2, o.z);
-                        unsafeAtomicAdd(slot + d0 + 3, o.w);
+                        unsafeAtomicAdd(slot + d0 + 0, o.x - o_start.x);
+                        unsafeAtomicAdd(slot + d0 + 1, o.y - o_start.y);
+                        unsafeAtomicAdd(slot + d0 + 2, o.z - o_start.z);
+                        unsafeAtomicAdd(slot + d0 + 3, o.w - o_start.w);
                     }
                     if (lig == 0) {
-                        unsafeAtomicAdd(slot + ka, og0);
-                        unsafeAtomicAdd(slot + ka + 1, og1);
+                        unsafeAtomicAdd(slot + ka, og0 - og_start.x);
+                        unsafeAtomicAdd(slot + ka + 1, og1 - og_start.y);
                         unsafeAtomicAdd(slot + ka + 2, tsum - hot_e0);        // squared errors of this chain
                         unsafeAtomicAdd(slot + ka + 3, (float)(hot_h >> 20)); // its ratings
                         unsafeAtomicAdd(slot + ka + 4, 1.0f);                 // one more chain
@@ -368,6 +371,8 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                         o = on;
                         og0 = ogn.x;
                         og1 = ogn.y;
+                        o_start = on; // (what a hot chain's change is measured against)
+                        og_start = ogn;
                         cur = id;
                     }
                     f4 g = gn;
@@ -548,7 +553,7 @@ __global__ __launch_bounds__(256) void fold_hot_rows(float *rows, float *acc, fl
     if (slot_i >= n_slots) return;
     const int stride = ka + HOT_EXTRA;
     float *const s0 = hot_acc + (size_t)slot_i * HOT_SUB * stride;
-    float ex[HOT_EXTRA] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f}; // sum G0-slot, sum G1-slot, squared errors, ratings, chains
+    float ex[HOT_EXTRA] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f}; // growth of both accumulator slots, squared errors, ratings, chains
     if (lane < HOT_EXTRA)
         for (int sub = 0; sub < HOT_SUB; ++sub) ex[0] += s0[(size_t)sub * stride + ka + lane];
     const float v = ex[0];
@@ -558,7 +563,7 @@ __global__ __launch_bounds__(256) void fold_hot_rows(float *rows, float *acc, fl
     if (!(n > 0.0f)) return; // the row had no chain in this round
     const int row = hot_row[slot_i];
     const float g00 = acc[(size_t)row * 2], g01 = acc[(size_t)row * 2 + 1];
-    const float A0 = fmaxf(ex[0] - n * g00, 0.0f), A1 = fmaxf(ex[1] - n * g01, 0.0f), E = ex[2], N = ex[3];
+    const float A0 = fmaxf(ex[0], 0.0f), A1 = fmaxf(ex[1], 0.0f), E = ex[2], N = ex[3];
     const float rn = 1.0f / n;
     const float r00 = __builtin_sqrtf(g00), r01 = __builtin_sqrtf(g01);
     // mean step sizes (/ 2 eta) of a sequential pass and of a chain, per accumulator slot
@@ -578,8 +583,7 @@ __global__ __launch_bounds__(256) void fold_hot_rows(float *rows, float *acc, fl
     for (int d = lane; d < (slow_only ? 8 : ka); d += 64) { // (epoch 0 moves the first eight factors only)
         float sum = 0.0f;
         for (int sub = 0; sub < HOT_SUB; ++sub) sum += s0[(size_t)sub * stride + d];
-        const float p0 = rows[(size_t)row * ka + d];
-        rows[(size_t)row * ka + d] = p0 + (d >= 8 ? sc1 : sc0) * (sum - n * p0);
+        rows[(size_t)row * ka + d] += (d >= 8 ? sc1 : sc0) * sum;
     }
     if (lane == 0) {
         acc[(size_t)row * 2] = g00 + A0;

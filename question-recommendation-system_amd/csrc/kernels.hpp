@@ -11,7 +11,7 @@ struct TaskDescD { uint64_t off; uint32_t nsteps; uint32_t pad; };
 
 constexpr int LOSS_SLOTS = 256; // the epoch loss is kept as this many partial sums
 constexpr int HOT_SUB = 8;      // a hot row's combine slot is kept as this many partial sums of (ka + HOT_EXTRA) floats:
-constexpr float HOT_S_GAIN = 8.0f; // fold_hot_rows: gain on the contraction estimate (calibrated, see there)
+constexpr float HOT_S_GAIN = 6.0f; // fold_hot_rows: gain on the contraction estimate (calibrated, see there)
 constexpr int HOT_EXTRA = 5;    // the row, then both accumulator slots, squared errors, ratings, chains
 
 // Arguments of one SGD round (= one launch = NS stripe-disjoint blocks).

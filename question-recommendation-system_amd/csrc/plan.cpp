@@ -181,11 +181,13 @@ void pack_visits(std::vector<Visit> &raw, int G, int target, int hot_len, BlockP
         L += v.len;
         if ((long long)v.len > hot_len) {
             long long nch = ((long long)v.len + hot_len - 1) / hot_len;
+            if (nch > 32767) nch = 32767; // the header entry counts chains in 15 bits: a monster row gets longer chains instead
             long long per = ((long long)v.len + nch - 1) / nch;
             long long made = 0;
             for (long long s = 0; s < v.len; s += per) ++made;
             const uint32_t slot = hot_slot_of_row ? (uint32_t)(*hot_slot_of_row)[v.own] : 0u;
-            if (made >= (1 << 15)) throw std::invalid_argument("a row is cut into 2^15 chains or more in one block");
+            if (made >= (1 << 15) || per >= (1 << 12))
+                throw std::invalid_argument("one row holds more than 134 M ratings of a block: more stripes (mfx_options.stripes)");
             for (long long s = 0; s < v.len; s += per)
                 visits.push_back({v.own, (uint32_t)std::min<long long>(per, v.len - s), v.start + (uint64_t)s,
                                   hot_slot_of_row ? (uint32_t)made : 0u, slot, (uint32_t)(s / per)});

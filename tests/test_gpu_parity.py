@@ -201,18 +201,24 @@ def test_full_size_properties(pkg):
 def test_other_epoch_counts_and_the_bench_sample(pkg, name, epochs):
     """The facade's default is 20 iterations (reference mf/mf.cpp:4546): configs[1] after 20 epochs, where a damping of the hot
     rows that is tuned at 12 epochs shows (it read +4.1 % before the lists stopped running their heavy rows first); and the
-    20 M-rating sample of configs[2] that bench.py times the CPU reference on."""
+    20 M-rating sample of configs[2] that bench.py times the CPU reference on.  The lock-free path is not deterministic: at
+    20 epochs single runs of configs[1] spread +-0.5 % (observed +2.0 .. +3.2 %), so the MEDIAN of three runs is held to the
+    tolerance."""
     import torch
     g = FULL[name]
     m, n, nnz, k = g["m"], g["n"], g["nnz"], g["k"]
     R = torch.empty(nnz * 3, dtype=torch.int32, device="cuda")
     pkg.synth_device(g["seed"], 0, nnz, m, n, R.data_ptr(), None, shard=0)
     torch.cuda.synchronize()
-    t = pkg.Trainer(None, m, n, opts=pkg.default_options(k=k), device_ptr=R.data_ptr(), nnz=nnz); t.init_model()
-    t.train(epochs)
-    rm = t.rmse(); t.close()
+    got = []
+    for _ in range(3):
+        t = pkg.Trainer(None, m, n, opts=pkg.default_options(k=k), device_ptr=R.data_ptr(), nnz=nnz); t.init_model()
+        t.train(epochs)
+        got.append(t.rmse()); t.close()
     want = g["rmse_after"][str(epochs)]
-    assert abs(rm - want) / want < RMSE_RTOL, (rm, want)
+    rm = float(np.median(got))
+    assert abs(rm - want) / want < RMSE_RTOL, (got, want)
+    assert max(got) - min(got) < 0.015 * want, got  # run-to-run spread stays small
 
 
 def test_slow_only_epoch_touches_first_eight_factors(pkg):

@@ -189,3 +189,21 @@ def test_no_gpu_means_error_not_fallback(pkg):
     arr = np.concatenate([[0, 1, 1, 8, 3.0], np.ones(16)]).astype(np.float32)
     with pytest.raises(pkg.MfxError, match="no HIP device"):
         pkg.predict_array(arr, [0, 0])
+
+
+def test_monster_row_gets_longer_chains(pkg, monkeypatch):
+    """A row with more ratings in a block than 2^15 chains of the usual length hold (configs[4]'s head item on one GPU:
+    4.5 M ratings per block): the header entry counts chains in 15 bits, so such a row gets longer chains instead of an error."""
+    m, n, nnz = 20000, 16, 1200000
+    rng = np.random.default_rng(0)
+    v = np.zeros(nnz, dtype=np.int64); v[:100000] = rng.integers(1, n, 100000)
+    R = pkg.as_nodes(rng.integers(0, m, nnz), v, rng.uniform(1, 5, nnz).astype(np.float32))
+    monkeypatch.setenv("MFX_HOT_LEN", "8")  # (the knob is read when the plan is built) 1.1 M / 8 blocks / 8 = 17 k ... per stripe
+    monkeypatch.setenv("MFX_STRIPES", "2")  # ... and two stripes make it 69 k chains of 8 for the head item's block
+    hp = pkg.HostPlan(R, m, n, k=8)
+    e = hp.entries
+    h = e[e["gat"] < -1]
+    code = -h["gat"].astype(np.int64) - 1
+    assert (e["gat"] >= 0).sum() == nnz
+    assert (code & 0x7FFF).max() <= 32767 and (code & 0x7FFF).max() > 20000   # capped, not failed
+    assert (h["r"].view(np.uint32) >> 20).max() > 8                           # ... by making the chains longer
