@@ -189,6 +189,21 @@ def auto_slots_per_rank(world):
     return 2 if world <= 4 else 1
 
 
+SMALL_SLOT = 4000000  # ratings per slot trainer below which the second slot per rank is not worth its order effect
+
+
+def slots_for(world, nnz_local):
+    """auto_slots_per_rank, but never two slots per rank when that would leave a slot trainer fewer than SMALL_SLOT ratings:
+    a slot trainer's block is then dealt over lists of a dozen steps, every visit runs beside every other one, and that
+    order alone costs final RMSE (4 ranks x configs[1], 20 epochs, oracle on the union problem 0.6580: one slot per rank,
+    2.5 M ratings per trainer, 0.6605; two slots, 1.25 M per trainer, 0.6898 --
+    profiles/experiments/r02_rotation_one_rank_compute.log)."""
+    c = auto_slots_per_rank(world)
+    if c > 1 and nnz_local // (c * world) < SMALL_SLOT:
+        c = 1
+    return c
+
+
 def _array_hash(a):
     """Order-sensitive 62-bit fingerprint of an int array (layout agreement checks)."""
     a = np.ascontiguousarray(a, dtype=np.int64)
@@ -209,8 +224,9 @@ class RotatingTrainer:
         dev = torch_device
         self.pkg, self.dist, self.world, self.rank, self.backend = pkg, dist, world, rank, backend
         live = dist is not None and world > 1
-        if not slots_per_rank:  # auto, see auto_slots_per_rank
-            slots_per_rank = auto_slots_per_rank(world)
+        if not slots_per_rank:  # auto, see slots_for
+            n_local = len(R_local) if isinstance(R_local, np.ndarray) else R_local.numel() // 3
+            slots_per_rank = slots_for(world, n_local)
         c = slots_per_rank if world > 1 else 1
         S = c * world
         self.c, self.S, self.m, self.n = c, S, m, n
