@@ -189,16 +189,17 @@ static int wgs_per_xcd_for(const mfx_options &opt, int m, int n, int ns, int cu_
 }
 
 // Stripes per side (= launches per epoch) and the launch width that goes with them.
-// Small problems (the stripe trainers of an N-GPU rotation, say): a launch has a floor of ~25 us (hand-over,
-// cold L2), so when a wave would get fewer than 32 steps per launch, half the stripes -- half the XCDs at work,
-// a quarter of the launches per epoch, four times the block -- is faster (one rank of N=8: 1.97 -> 1.46
-// ms/epoch, N=4: 1.30 -> 1.08; profiles/experiments/r01_substripes.log).
+// Round 1 took half the stripes for small problems (a wave with fewer than 32 steps per launch: half the XCDs at work, a quarter
+// of the launches, four times the block -- one rank of N=8: 1.97 -> 1.46 ms per epoch).  It costs parity: with four times
+// the block a heavy row has four times the chains per fold and half the folds per epoch, and the damped fold then under-moves
+// it (slot trainer of 1.25 M ratings, 20 epochs, order emulation: +3.4 % with 4 stripes, +0.7 % with 8; four ranks on one
+// GPU against the oracle on the union problem: +4.8 % vs +0.5 %).  MFX_HALF_STRIPES=1 brings the rule back for experiments.
 static int choose_stripes(const mfx_options &opt, long long nnz, int m, int n, int xcd_count, int cu_per_xcd,
                           int *wgs_per_xcd, int *waves_per_wg)
 {
-    int stripes = opt.stripes > 0 ? opt.stripes : env_int("MFX_STRIPES", xcd_count);
+    int stripes = opt.stripes > 0 ? opt.stripes : std::max(1, env_int("MFX_STRIPES", xcd_count));
     *wgs_per_xcd = wgs_per_xcd_for(opt, m, n, stripes, cu_per_xcd, waves_per_wg);
-    if (opt.stripes <= 0 && env_int("MFX_STRIPES", 0) <= 0 && stripes >= 8) {
+    if (env_int("MFX_HALF_STRIPES", 0) != 0 && opt.stripes <= 0 && env_int("MFX_STRIPES", 0) <= 0 && stripes >= 8) {
         const int G = 64 / mfx::lanes_for(mfx::k_aligned(opt.k));
         const long long waves = (long long)*wgs_per_xcd * *waves_per_wg;
         if (nnz / ((long long)stripes * stripes * G * std::max<long long>(1, waves)) < 32) {

@@ -189,15 +189,15 @@ def auto_slots_per_rank(world):
     return 2 if world <= 4 else 1
 
 
-SMALL_SLOT = 4000000  # ratings per slot trainer below which the second slot per rank is not worth its order effect
+SMALL_SLOT = 1000000  # ratings per slot trainer below which the second slot per rank is not taken
 
 
 def slots_for(world, nnz_local):
-    """auto_slots_per_rank, but never two slots per rank when that would leave a slot trainer fewer than SMALL_SLOT ratings:
-    a slot trainer's block is then dealt over lists of a dozen steps, every visit runs beside every other one, and that
-    order alone costs final RMSE (4 ranks x configs[1], 20 epochs, oracle on the union problem 0.6580: one slot per rank,
-    2.5 M ratings per trainer, 0.6605; two slots, 1.25 M per trainer, 0.6898 --
-    profiles/experiments/r02_rotation_one_rank_compute.log)."""
+    """auto_slots_per_rank, but never two slots per rank when that would leave a slot trainer fewer than SMALL_SLOT ratings
+    (a block is then dealt over lists of a few steps and every visit runs beside every other one).  Measured with four
+    ranks x configs[1] (1.25 M ratings per slot trainer at two slots per rank), 20 epochs, oracle on the union problem 0.6580:
+    one slot per rank 0.6604, two slots 0.6645 -- and 0.6898 while small trainers still took half the stripes
+    (trainer.cpp: choose_stripes; profiles/experiments/r02_rotation_one_rank_compute.log)."""
     c = auto_slots_per_rank(world)
     if c > 1 and nnz_local // (c * world) < SMALL_SLOT:
         c = 1
