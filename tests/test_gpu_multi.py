@@ -44,16 +44,17 @@ def _rank(rank, world, port, cfg, q):
     q.put((rank, got, sorted(stripes), sizes))
 
 
-@pytest.mark.parametrize("c", [2, 1])
-def test_two_ranks_rotate_matches_oracle(pkg, orc, c):
-    """configs[3]'s shape scaled down (two user shards of one problem, items shared), trained by two ranks that pass
-    the item slots round the ring: final RMSE over ALL ratings vs the one-worker oracle on the union problem."""
+@pytest.mark.parametrize("world,c,iters", [(2, 2, 8), (2, 1, 8), (4, 2, 12)])
+def test_two_ranks_rotate_matches_oracle(pkg, orc, world, c, iters):
+    """configs[3]'s shape scaled down (user shards of one problem, items shared), trained by two (four) ranks that pass
+    the item slots round the ring: final RMSE over ALL ratings vs the one-worker oracle on the union problem.  The
+    four-rank case has eight slot trainers of 375 k ratings per rank -- the regime where round 1's "half the stripes for small
+    problems" broke parity (+4.8 % at configs[1] per rank)."""
     import torch.multiprocessing as mp
-    world = 2
-    m, n, nnz, k, iters = 40000, 30000, 3000000, 32, 8
+    m, n, nnz, k = 40000, 30000, 3000000, 32
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33000 + (os.getpid() * 3 + c) % 2000
+    port = 33000 + (os.getpid() * 3 + c + 7 * world) % 2000
     procs = [ctx.Process(target=_rank, args=(r, world, port, (m, n, nnz, k, iters, c), q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -61,9 +62,11 @@ def test_two_ranks_rotate_matches_oracle(pkg, orc, c):
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    assert res[0][1] == pytest.approx(res[1][1], rel=1e-9)         # both ranks report the job-wide figure
-    assert res[0][2] == res[1][2] and len(res[0][2]) == 1          # ONE stripe count for the whole job
-    assert sum(res[0][3]) == nnz and sum(res[1][3]) == nnz         # every rating sits in exactly one slot trainer
+    for r in range(1, world):
+        assert res[0][1] == pytest.approx(res[r][1], rel=1e-9)     # every rank reports the job-wide figure
+        assert res[0][2] == res[r][2] and len(res[0][2]) == 1      # ONE stripe count for the whole job
+        assert sum(res[r][3]) == nnz                               # every rating sits in exactly one slot trainer
+    assert sum(res[0][3]) == nnz
     # the union problem for the oracle: rank r's users are rows [r*m, (r+1)*m)
     parts = []
     for r in range(world):
