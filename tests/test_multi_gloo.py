@@ -168,3 +168,12 @@ def test_stripe_count_is_pinned_per_job(monkeypatch):
     assert a.view.stripes == b.view.stripes == 4  # an explicit stripe count wins over the size heuristic
     o.stripes = 8
     assert pkg.stripes_for(o, 1000, m, n) == 8
+
+
+def test_slots_per_rank_rule():
+    """Two slots per rank (transfer hidden) up to four ranks, one beyond, and one whenever a second slot would leave a slot
+    trainer under a million ratings."""
+    multi = _load_multi()
+    assert [multi.auto_slots_per_rank(w) for w in (1, 2, 4, 5, 8)] == [2, 2, 2, 1, 1]
+    assert multi.slots_for(4, 100000000) == 2 and multi.slots_for(8, 100000000) == 1
+    assert multi.slots_for(4, 10000000) == 2 and multi.slots_for(4, 7000000) == 1 and multi.slots_for(2, 3000000) == 1

@@ -112,3 +112,46 @@ def test_edge_cases(orc):
     # k that is not a multiple of 8 pads internally and shrinks back (mf.cpp:959, 1057-1074)
     arr5 = orc.train(R, 3, 4, k=5, iters=2)
     assert len(arr5) == 5 + 7 * 5 and arr5[3] == 5
+
+
+def test_order_study_entry_is_the_pinned_trainer(orc):
+    """orc_train_order with the reference's order (all zeros) is orc_train: same code path, bit for bit."""
+    rng = np.random.default_rng(5)
+    m, n, nnz = 300, 200, 5000
+    idx = rng.choice(m * n, nnz, replace=False)
+    R = np.zeros(nnz, dtype=orc.NODE)
+    R["u"], R["v"] = idx // n, idx % n
+    R["r"] = rng.uniform(1, 5, nnz).astype(np.float32)
+    a = orc.train(R, m, n, k=16, iters=4)
+    b = orc.train(R, m, n, k=16, iters=4, order=(0, 0, 0))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    c = orc.train(R, m, n, k=16, iters=4, order=(2, 1, 7))  # another order: another result, same size
+    assert c.shape == a.shape and not np.array_equal(a.view(np.uint32), c.view(np.uint32))
+
+
+@pytest.mark.parametrize("k", [8, 40])
+def test_plan_order_emulation_uses_the_pinned_update(pkg, orc, k):
+    """oracle/plan_order.c walks a GPU plan with orc_sgd_one.  On ratings that share no row the order cannot matter, so one
+    epoch of it must equal orc_sgd_one applied rating by rating -- bit for bit -- whatever the plan's lists look like."""
+    m = n = 2000
+    rng = np.random.default_rng(k)
+    R = pkg.as_nodes(np.arange(m), rng.permutation(n), rng.uniform(1, 5, m).astype(np.float32))
+    hp = pkg.HostPlan(R, m, n, k=k)
+    v = hp.view
+    P, Q = hp.init_factors()
+    PG, QG = np.ones((m, 2), dtype=np.float32), np.ones((n, 2), dtype=np.float32)
+    Pe, Qe, PGe, QGe = P.copy(), Q.copy(), PG.copy(), QG.copy()
+    sc = np.float32(v.scale)
+    lam = np.float32(0.1) / sc
+    ent, tsk, sp = (np.ascontiguousarray(x) for x in (hp.entries, hp.tasks, hp.slot_task_ptr))
+    loss = np.zeros(1)
+    orc.lib().orc_plan_order_train(ent.ctypes.data, tsk.ctypes.data, sp.ctypes.data, v.stripes, v.ratings_per_wave, v.k_aligned,
+                                   v.owner_is_q, Pe.ctypes.data, Qe.ctypes.data, PGe.ctypes.data, QGe.ctypes.data, v.n_hot_slots,
+                                   lam, lam, 0.1, 1, 1, orc.CHAIN_FOLD, orc.RSQRT_EXACT, orc.RK_AS_BUILT, loss.ctypes.data)
+    Ri = R.copy()
+    Ri["u"], Ri["v"] = hp.p_map[R["u"]], hp.q_map[R["v"]]
+    Ri["r"] = (R["r"] * (np.float32(1.0) / sc)).astype(np.float32)
+    want = orc.sgd_apply(P, Q, PG, QG, Ri, v.k_aligned, float(lam), float(lam), 0.1, False)
+    for got, ref in ((Pe, P), (Qe, Q), (PGe, PG), (QGe, QG)):
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert abs(loss[0] - want) <= 1e-6 * want
