@@ -659,7 +659,8 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
         if (!p.round_hot.empty() && !p.round_hot[(size_t)r]) continue; // no chain in this round: nothing to fold
         HIP_TRY(mfx::launch_fold_hot(a.own_rows, a.own_acc, t->dHotAcc.p, t->dHotRow.p, (int)p.n_hot_slots, p.ka, a.eta,
                                      a.rk1, a.slow_only, env_int("MFX_FOLD_MODE", 0),
-                                     (float)env_int("MFX_HOT_S_GAIN", (int)mfx::HOT_S_GAIN), s));
+                                     (float)env_int("MFX_HOT_S_GAIN", (int)mfx::HOT_S_GAIN),
+                                     (float)env_int("MFX_HOT_S_N0", (int)mfx::HOT_S_N0), s));
     }
     if (e1) {
         HIP_TRY(hipEventRecord(e1, s));
