@@ -573,12 +573,11 @@ __global__ __launch_bounds__(256) void fold_hot_rows(float *rows, float *acc, fl
     const float c0 = cq * A0 * 8.0f, c1 = cq * A1 / rk1;
     const float Sseq = ts0 * c0 + ts1 * c1, Sch = (tc0 * c0 + tc1 * c1) * rn;
     auto damp = [](float S) { return S > 1e-3f ? (1.0f - __expf(-S)) / S : 1.0f - 0.5f * S; };
-    // HOT_S_GAIN: while the chains hold the row still, the rows on the other side of the row's ratings all move against
-    // the same unmoved value, so the error shrinks faster than the row's own curvature says; the factor was calibrated
-    // on the order emulation (oracle/plan_order.c: final RMSE of the plan's order with chains vs without, three data
-    // sets within +-0.4 %; tests/tools/order_study.py)
-    // (n0 > 0: the gain grows with the chain count, g * sqrt(n / n0 + 1) -- the more ratings a row has, the more a batch fold
-    //  out-fits the sequential pass it stands for)
+    // The gain on S (HOT_S_GAIN, growing with the chain count n as g * sqrt(n / n0 + 1), HOT_S_N0): private row copies are
+    // not a sequential pass -- a batch-like fold is a lower-variance estimator than a pass that tracks the last ratings it
+    // saw, the more so the more ratings the row has -- and under-moving the row is what stands in for that.  Calibrated
+    // on the order emulation (oracle/plan_order.c, tests/tools/order_study.py) and on the GPU over configs[1] at 12 and 20
+    // epochs, configs[2] at 8, 12 and 20 and its 20 M sample (DESIGN.md 4 "Hot rows").
     const float geff = n0 > 0.0f ? s_gain * __builtin_sqrtf(n / n0 + 1.0f) : s_gain;
     const float phi = damp(geff * Sseq) / damp(geff * Sch); // (1-exp(-S)) / (n (1-exp(-S/n))) in the symmetric case
     // fold_mode 0: the damped sum above; 1 (experiment): the row becomes the MEAN of the chains' end states
