@@ -11,6 +11,11 @@ CASES_DENSE = [  # same shape as configs[1], three widths
     ("1M x 500k 50M k=8", 1000000, 500000, 50000000, 8, 6),
     ("2x rows k=32", 200000, 100000, 10000000, 32, 12),
 ]
+CASES_PARITY = [  # the fixtures of tests/golden/full_size.json (oracle: 0.8363 / 0.7190 / 0.8791 after these epochs)
+    ("configs[1] @12", 100000, 50000, 10000000, 32, 12),
+    ("configs[1] @20", 100000, 50000, 10000000, 32, 20),
+    ("configs[2] @12", 1000000, 500000, 100000000, 64, 12),
+]
 CASES = [  # name, m, n, nnz, k, epochs
     ("C2 100k x 50k 10M k=32", 100000, 50000, 10000000, 32, 12),
     ("C3-like 1M x 300k 100M k=64", 1000000, 300000, 100000000, 64, 6),
@@ -39,6 +44,9 @@ print("AB " + json.dumps(out), flush=True)
 libs = sys.argv[1:] or ["lib"]
 if libs[0] == "--dense":
     CASES = CASES_DENSE
+    libs = libs[1:]
+elif libs[0] == "--parity":
+    CASES = CASES_PARITY
     libs = libs[1:]
 res = {}
 for lib in libs:
