@@ -69,10 +69,11 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
     const int study_dump_minn = getenv("ORC_STUDY_DUMP_MINN") ? atoi(getenv("ORC_STUDY_DUMP_MINN")) : 0;
     int dumped = 0;
     const double study_blend = getenv("ORC_STUDY_BLEND") ? atof(getenv("ORC_STUDY_BLEND")) : 0.0;
-    const double study_smul = getenv("ORC_STUDY_SMUL") ? atof(getenv("ORC_STUDY_SMUL")) : 4.0; /* = HOT_S_GAIN of kernels.hpp */
+    const double study_smul = getenv("ORC_STUDY_SMUL") ? atof(getenv("ORC_STUDY_SMUL")) : 1.0; /* = HOT_S_GAIN of kernels.hpp */
     const double study_rgain = getenv("ORC_STUDY_RGAIN") ? atof(getenv("ORC_STUDY_RGAIN")) : 1.0;
-    const int study_nform = getenv("ORC_STUDY_NFORM") ? atoi(getenv("ORC_STUDY_NFORM")) : 2; /* as the kernel: gain * sqrt(n / n0 + 1) */
-    const double study_n0 = getenv("ORC_STUDY_N0") ? atof(getenv("ORC_STUDY_N0")) : 32.0; /* = HOT_S_N0 of kernels.hpp */
+    const int study_nform = getenv("ORC_STUDY_NFORM") ? atoi(getenv("ORC_STUDY_NFORM")) : 2; /* as the kernel: gain * (n / n0 + 1)^npow */
+    const double study_n0 = getenv("ORC_STUDY_N0") ? atof(getenv("ORC_STUDY_N0")) : 2.0; /* = HOT_S_N0 of kernels.hpp */
+    const double study_npow = getenv("ORC_STUDY_NPOW") ? atof(getenv("ORC_STUDY_NPOW")) : 0.5; /* = HOT_S_POW of kernels.hpp */
     const int study_avg = getenv("ORC_STUDY_AVG") != NULL;
     const double study_gain = getenv("ORC_STUDY_GAIN") ? atof(getenv("ORC_STUDY_GAIN")) : 1.0;
     pl_list *lists;
@@ -237,7 +238,7 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
                                                         Sch = (tc0 * (c0 + 8 * reg) + tc1 * (c1 + (ka - 8) * reg)) * rn;
                                             const float nn = (float)(L->hot_n & 0x7FFF);
                                             const float geff = (float)study_smul * (study_nform == 1 ? fmaxf(1.0f, nn / (float)study_n0)
-                                                                                    : study_nform == 2 ? sqrtf(nn / (float)study_n0 + 1.0f) : 1.0f);
+                                                                                    : study_nform == 2 ? powf(nn / (float)study_n0 + 1.0f, (float)study_npow) : 1.0f);
                                             const float phi = damp(geff * Sseq) / damp(geff * Sch);
                                             if (study_dump && ep == study_dump && (L->hot_n & 0x7FFF) >= study_dump_minn && dumped < 4000 && (dumped++ % 4) == 0)
                                                 fprintf(stderr, "fold ep %d n %d N %.0f G0 %.1f %.1f A %.2f %.2f E %.1f Sseq %.3f Sch %.3f phi %.3f sc %.3f %.3f\n", ep,

@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
 // 2 eta / (sqrt(G_end) + sqrt(G0))), the curvature |q|^2 from the accumulator growth over the squared errors
 // (A = rk * sum e^2 |q|^2): nothing extra is computed per rating.
 __global__ __launch_bounds__(256) void fold_hot_rows(float *rows, float *acc, float *hot_acc, const int *hot_row,
-                                                     int n_slots, int ka, float eta, float rk1, int slow_only, int fold_mode, float s_gain, float n0)
+                                                     int n_slots, int ka, float eta, float rk1, int slow_only, int fold_mode, float s_gain, float n0, float npow)
 {
     const int lane = threadIdx.x & 63;
     const int slot_i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void fold_hot_rows(float *rows, float *acc, fl
     // saw, the more so the more ratings the row has -- and under-moving the row is what stands in for that.  Calibrated
     // on the order emulation (oracle/plan_order.c, tests/tools/order_study.py) and on the GPU over configs[1] at 12 and 20
     // epochs, configs[2] at 8, 12 and 20 and its 20 M sample (DESIGN.md 4 "Hot rows").
-    const float geff = n0 > 0.0f ? s_gain * __builtin_sqrtf(n / n0 + 1.0f) : s_gain;
+    const float geff = n0 > 0.0f ? s_gain * __powf(n / n0 + 1.0f, npow) : s_gain;
     const float phi = damp(geff * Sseq) / damp(geff * Sch); // (1-exp(-S)) / (n (1-exp(-S/n))) in the symmetric case
     // fold_mode 0: the damped sum above; 1 (experiment): the row becomes the MEAN of the chains' end states
     const float sc0 = fold_mode == 1 ? rn : phi * ts0 / tc0, sc1 = fold_mode == 1 ? rn : phi * ts1 / tc1;
@@ -853,11 +853,11 @@ hipError_t launch_sgd_round(int lanes, const RoundArgs &a, int grid, hipStream_t
 }
 
 hipError_t launch_fold_hot(float *rows, float *acc, float *hot_acc, const int *hot_row, int n_slots, int ka, float eta,
-                           float rk1, int slow_only, int fold_mode, float s_gain, float n0, hipStream_t s)
+                           float rk1, int slow_only, int fold_mode, float s_gain, float n0, float npow, hipStream_t s)
 {
     if (n_slots <= 0) return hipSuccess;
     hipLaunchKernelGGL(fold_hot_rows, dim3((n_slots + 3) / 4), dim3(256), 0, s, rows, acc, hot_acc, hot_row, n_slots, ka,
-                       eta, rk1, slow_only, fold_mode, s_gain, n0);
+                       eta, rk1, slow_only, fold_mode, s_gain, n0, npow);
     return hipGetLastError();
 }
 

@@ -11,8 +11,9 @@ struct TaskDescD { uint64_t off; uint32_t nsteps; uint32_t pad; };
 
 constexpr int LOSS_SLOTS = 256; // the epoch loss is kept as this many partial sums
 constexpr int HOT_SUB = 8;      // a hot row's combine slot is kept as this many partial sums of (ka + HOT_EXTRA) floats:
-constexpr float HOT_S_GAIN = 4.0f; // fold_hot_rows: gain on the contraction estimate (calibrated, see there)
-constexpr float HOT_S_N0 = 32.0f;  // > 0: the gain grows with the chain count, g * sqrt(n / n0 + 1)
+constexpr float HOT_S_GAIN = 1.0f; // fold_hot_rows: gain on the contraction estimate (calibrated, see there)
+constexpr float HOT_S_N0 = 2.0f;   // > 0: the gain grows with the chain count, g * (n / n0 + 1)^HOT_S_POW
+constexpr float HOT_S_POW = 0.5f;
 constexpr int HOT_EXTRA = 5;    // the row, then both accumulator slots, squared errors, ratings, chains
 
 // Arguments of one SGD round (= one launch = NS stripe-disjoint blocks).
@@ -46,7 +47,7 @@ struct RoundArgs {
 
 hipError_t launch_sgd_round(int lanes, const RoundArgs &a, int grid, hipStream_t s);
 hipError_t launch_fold_hot(float *rows, float *acc, float *hot_acc, const int *hot_row, int n_slots, int ka, float eta,
-                           float rk1, int slow_only, int fold_mode, float s_gain, float n0, hipStream_t s);
+                           float rk1, int slow_only, int fold_mode, float s_gain, float n0, float npow, hipStream_t s);
 hipError_t launch_visibility_probe(int *ticket, float *row, int *flag, int *ack, int rounds, int *out, int grid, hipStream_t s);
 hipError_t launch_probe_xcc(unsigned *mask, int grid, hipStream_t s);
 hipError_t launch_sq_err_entries(int lanes, const float *own_rows, const float *gat_rows,

@@ -47,6 +47,12 @@ int env_int(const char *name, int dflt)
     return (s && *s) ? atoi(s) : dflt;
 }
 
+float env_flt(const char *name, float dflt)
+{
+    const char *s = getenv(name);
+    return (s && *s) ? (float)atof(s) : dflt;
+}
+
 template <class T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
@@ -659,8 +665,8 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
         if (!p.round_hot.empty() && !p.round_hot[(size_t)r]) continue; // no chain in this round: nothing to fold
         HIP_TRY(mfx::launch_fold_hot(a.own_rows, a.own_acc, t->dHotAcc.p, t->dHotRow.p, (int)p.n_hot_slots, p.ka, a.eta,
                                      a.rk1, a.slow_only, env_int("MFX_FOLD_MODE", 0),
-                                     (float)env_int("MFX_HOT_S_GAIN", (int)mfx::HOT_S_GAIN),
-                                     (float)env_int("MFX_HOT_S_N0", (int)mfx::HOT_S_N0), s));
+                                     env_flt("MFX_HOT_S_GAIN", mfx::HOT_S_GAIN),
+                                     env_flt("MFX_HOT_S_N0", mfx::HOT_S_N0), env_flt("MFX_HOT_S_POW", mfx::HOT_S_POW), s));
     }
     if (e1) {
         HIP_TRY(hipEventRecord(e1, s));
