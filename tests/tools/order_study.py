@@ -5,8 +5,8 @@
       0 (last writer wins, round 1); HostPlan options e.g. identity_maps=2 owner_side=1 stripes=16
 
 Prints the one-worker oracle in the reference's order (orc_train), then oracle/plan_order.c -- the same per-rating update walked in
-the GPU plan's own order -- for every chain mode asked for.  Study knobs of plan_order.c (environment): ORC_STUDY_SMUL (gain on the
-fold's contraction estimate, default = the kernel's HOT_S_GAIN), ORC_STUDY_AVG=1 (mean of the chains' end states), ORC_STUDY_DUMP=<epoch>.
+the GPU plan's own order -- for every chain mode asked for.  Study knobs of plan_order.c (environment): ORC_STUDY_SMUL / ORC_STUDY_N0 /
+ORC_STUDY_NPOW (the fold's gain, gain * (chains / n0 + 1)^npow; defaults = the kernel's HOT_S_GAIN, HOT_S_N0, HOT_S_POW), ORC_STUDY_AVG=1 (mean of the chains' end states), ORC_STUDY_DUMP=<epoch>.
 Results of round 2: profiles/experiments/r02_plan_order_emulation.log, r02_oracle_order_sensitivity.log."""
 import os
 import sys
