@@ -3,7 +3,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -104,18 +106,36 @@ void pack_class(const std::vector<Visit> &visits, size_t vbeg, size_t vend, int 
     if (force_ntasks > 0) ntasks = force_ntasks;
     if (ntasks < 1) ntasks = 1;
     const long long NG = ntasks * G;
-    typedef std::pair<uint32_t, uint32_t> LB; // (load, list)
-    std::priority_queue<LB, std::vector<LB>, std::greater<LB>> heap;
-    for (long long b = 0; b < NG; ++b) heap.push({0u, (uint32_t)b});
-    std::vector<std::vector<uint32_t>> list_visits(NG);
+    // Longest-processing-time-first: every visit goes to the list with the smallest load (ties: smallest list index).
+    // A binary min-heap of (load << 32 | list) keys, all distinct; the top is replaced and sifted down (no pop + push).
+    std::vector<uint64_t> heap((size_t)NG);
+    for (long long b = 0; b < NG; ++b) heap[(size_t)b] = (uint64_t)b; // ascending = a valid heap
     std::vector<uint32_t> load(NG, 0);
+    // the visits of a list as a chain of indices (head / tail per list, next per visit), in packing order
+    const uint32_t NIL = 0xFFFFFFFFu;
+    std::vector<uint32_t> head((size_t)NG, NIL), tail((size_t)NG, NIL), next(vend - vbeg, NIL), count((size_t)NG, 0);
     for (size_t vi = vbeg; vi < vend; ++vi) {
-        LB top = heap.top();
-        heap.pop();
-        list_visits[top.second].push_back((uint32_t)vi);
-        load[top.second] = top.first + steps_of(visits[vi]);
-        heap.push({load[top.second], top.second});
+        const uint64_t top = heap[0];
+        const uint32_t lst = (uint32_t)top;
+        if (tail[lst] == NIL) head[lst] = (uint32_t)(vi - vbeg);
+        else next[tail[lst]] = (uint32_t)(vi - vbeg);
+        tail[lst] = (uint32_t)(vi - vbeg);
+        ++count[lst];
+        const uint64_t key = top + ((uint64_t)steps_of(visits[vi]) << 32);
+        load[lst] = (uint32_t)(key >> 32);
+        size_t i = 0;
+        const size_t n = (size_t)NG;
+        for (;;) { // sift the new key down
+            size_t c = 2 * i + 1;
+            if (c >= n) break;
+            if (c + 1 < n && heap[c + 1] < heap[c]) ++c;
+            if (heap[c] >= key) break;
+            heap[i] = heap[c];
+            i = c;
+        }
+        heap[i] = key;
     }
+    std::vector<uint32_t> lv; // the visits of the list being emitted
     std::vector<uint32_t> order(NG);
     for (long long b = 0; b < NG; ++b) order[b] = (uint32_t)b;
     std::stable_sort(order.begin(), order.end(),
@@ -138,16 +158,19 @@ void pack_class(const std::vector<Visit> &visits, size_t vbeg, size_t vend, int 
             // row id, mf.cpp:843-852), worth -0.6 % (20 M sample) to -1.9 % (configs[2]) of final RMSE by itself in the
             // order emulation.  MFX_LIST_ORDER: 0 as packed, 1 by owner row id (default: the reference's own
             // order inside a block; +0.9 % epoch time on configs[2]), 2 scattered by a hash (same fit, +3.3 % time).
+            lv.clear();
+            lv.reserve(count[lst]);
+            for (uint32_t x = head[lst]; x != NIL; x = next[x]) lv.push_back((uint32_t)(x + vbeg));
             if (list_order == 1)
-                std::sort(list_visits[lst].begin(), list_visits[lst].end(), [&](uint32_t a, uint32_t b) {
+                std::sort(lv.begin(), lv.end(), [&](uint32_t a, uint32_t b) {
                     return visits[a].own != visits[b].own ? visits[a].own < visits[b].own : visits[a].idx < visits[b].idx;
                 });
             else if (list_order == 2)
-                std::sort(list_visits[lst].begin(), list_visits[lst].end(), [&](uint32_t a, uint32_t b) {
+                std::sort(lv.begin(), lv.end(), [&](uint32_t a, uint32_t b) {
                     const uint32_t ha = (visits[a].own * 2654435761u) ^ (visits[a].idx * 40503u), hb = (visits[b].own * 2654435761u) ^ (visits[b].idx * 40503u);
                     return ha != hb ? ha < hb : a < b;
                 });
-            for (uint32_t vi : list_visits[lst]) {
+            for (uint32_t vi : lv) {
                 const Visit &v = visits[vi];
                 if (v.nch) { // hot chain: a header entry first
                     out.headers.push_back({base + (uint64_t)step * G + g, v.own, v.nch, v.hot | (v.len << 20), v.idx});
@@ -196,8 +219,21 @@ void pack_visits(std::vector<Visit> &raw, int G, int target, int hot_len, BlockP
             visits.push_back(v);
         }
     }
-    std::stable_sort(visits.begin(), visits.end(),
-                     [](const Visit &a, const Visit &b) { return a.len > b.len; });
+    // longest first, equal lengths in their given order: a counting sort (lengths are at most hot_len unless a monster
+    // row got longer chains), the comparison sort otherwise
+    uint32_t max_len = 0;
+    for (const Visit &v : visits) max_len = std::max(max_len, v.len);
+    if (max_len <= 65536u) {
+        std::vector<size_t> at((size_t)max_len + 2, 0);
+        for (const Visit &v : visits) at[(size_t)(max_len - v.len) + 1]++;
+        for (size_t i = 1; i < at.size(); ++i) at[i] += at[i - 1];
+        std::vector<Visit> sorted(visits.size());
+        for (const Visit &v : visits) sorted[at[(size_t)(max_len - v.len)]++] = v;
+        visits.swap(sorted);
+    } else {
+        std::stable_sort(visits.begin(), visits.end(),
+                         [](const Visit &a, const Visit &b) { return a.len > b.len; });
+    }
 
     // Graded task sizes: the first half of the work goes into full-size tasks, then a
     // quarter at half size, ... so the waves that drain the block's queue last are holding
@@ -242,11 +278,19 @@ void plan_sizes(long long nnz, int NB, int G, const PlanConfig &cfg, int &target
 }
 
 void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig &cfg, Plan &p,
-                 std::vector<Placement> &places, int threads)
+                 PlaceVec &places, int threads)
 {
     const int NS = p.ns, NB = NS * NS, G = p.groups;
     int target, hot_len;
     plan_sizes(p.nnz, NB, G, cfg, target, hot_len);
+    const bool timing = getenv("MFX_PLAN_TIMING") && atoi(getenv("MFX_PLAN_TIMING")) != 0;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "mfx plan:   %-26s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     // Tasks per wave.  A block is cut into (tasks per wave) x (waves of its XCD) tasks of equal load
     // (longest-first packing), handed out through the block's cursor.  One task per wave when a wave's
     // share of the launch is short -- every hand-over costs a chain of misses -- and two when it is long,
@@ -260,17 +304,35 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
     std::vector<int> hot_slot((size_t)(p.owner_is_q ? p.n : p.m), -1);
     p.n_hot_slots = 0;
     p.hot_rows.clear();
-    for (int b = 0; b < NB; ++b)
-        for (const Visit &v : block_visits[b])
-            if ((long long)v.len > hot_len && hot_slot[v.own] < 0) {
-                hot_slot[v.own] = (int)p.n_hot_slots++;
-                p.hot_rows.push_back((int)v.own);
+    {
+        // rows cut in each block (found in parallel), numbered in block order, then visit order
+        std::vector<std::vector<uint32_t>> cut(NB);
+        std::atomic<int> nb(0);
+        auto scan = [&]() {
+            for (;;) {
+                const int b = nb.fetch_add(1);
+                if (b >= NB) break;
+                for (const Visit &v : block_visits[b])
+                    if ((long long)v.len > hot_len) cut[b].push_back(v.own);
             }
+        };
+        std::vector<std::thread> pool;
+        const int nt = std::max(1, std::min(threads, NB));
+        for (int t = 0; t < nt; ++t) pool.emplace_back(scan);
+        for (auto &th : pool) th.join();
+        for (int b = 0; b < NB; ++b)
+            for (uint32_t own : cut[b])
+                if (hot_slot[own] < 0) {
+                    hot_slot[own] = (int)p.n_hot_slots++;
+                    p.hot_rows.push_back((int)own);
+                }
+    }
     if (p.n_hot_slots >= (1 << 20) || hot_len >= (1 << 12))
         throw std::invalid_argument("too many hot rows / too long chains for the header entry format");
     // experiment knob: round 1's behaviour (chains overwrite the row, the last writer wins: no headers, no fold)
     const char *lww = getenv("MFX_HOT_LWW");
     const bool hot_lww = lww && *lww && atoi(lww) != 0;
+    lap("hot slots");
     std::vector<BlockPack> packs(NB);
     {
         std::vector<int> blocks(NB);
@@ -292,6 +354,7 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
         for (int t = 0; t < nt; ++t) pool.emplace_back(work);
         for (auto &th : pool) th.join();
     }
+    lap("pack blocks (threads)");
     // concatenate in (round, slot) order: round r, slot s -> owner stripe s,
     // gathered stripe (s + r) mod NS, so the NS slots of a round are stripe-disjoint
     size_t tot_t = 0, tot_p = 0;
@@ -301,37 +364,62 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
         p.n_hot_rows += o.hot;
         p.n_padding += o.padding;
     }
-    p.headers.clear();
     p.round_hot.assign((size_t)NS, 0);
-    p.tasks.clear();
-    p.tasks.reserve(tot_t);
-    places.clear();
-    places.reserve(tot_p);
     p.slot_task_ptr.assign((size_t)NB + 1, 0);
-    uint64_t ebase = 0;
+    // bases of every (round, slot) piece, then the pieces are copied side by side
+    std::vector<uint64_t> e_base((size_t)NB + 1, 0);
+    std::vector<size_t> t_base((size_t)NB + 1, 0), p_base((size_t)NB + 1, 0), h_base((size_t)NB + 1, 0);
     for (int r = 0; r < NS; ++r)
         for (int s = 0; s < NS; ++s) {
-            BlockPack &o = packs[s * NS + (s + r) % NS];
-            for (TaskDesc td : o.tasks) {
-                td.off += ebase;
-                p.tasks.push_back(td);
-            }
-            for (Placement pl : o.places) {
-                pl.dst += ebase;
-                places.push_back(pl);
-            }
+            const BlockPack &o = packs[s * NS + (s + r) % NS];
+            const size_t i = (size_t)r * NS + s;
+            e_base[i + 1] = e_base[i] + o.n_entries;
+            t_base[i + 1] = t_base[i] + o.tasks.size();
+            p_base[i + 1] = p_base[i] + o.places.size();
+            h_base[i + 1] = h_base[i] + o.headers.size();
             if (!o.headers.empty()) p.round_hot[r] = 1;
-            for (HeaderRec h : o.headers) {
-                h.dst += ebase;
-                p.headers.push_back(h);
-            }
-            ebase += o.n_entries;
-            p.slot_task_ptr[(size_t)r * NS + s + 1] = (long long)p.tasks.size();
-            std::vector<TaskDesc>().swap(o.tasks);
-            std::vector<Placement>().swap(o.places);
-            std::vector<HeaderRec>().swap(o.headers);
+            p.slot_task_ptr[i + 1] = (long long)t_base[i + 1];
         }
+    p.tasks.resize(tot_t);
+    places.resize(tot_p);
+    p.headers.resize(h_base[NB]);
+    {
+        std::atomic<int> nb(0);
+        auto copy = [&]() {
+            for (;;) {
+                const int i = nb.fetch_add(1);
+                if (i >= NB) break;
+                const int r = i / NS, s = i % NS;
+                BlockPack &o = packs[s * NS + (s + r) % NS];
+                const uint64_t eb = e_base[i];
+                TaskDesc *td = p.tasks.data() + t_base[i];
+                for (size_t j = 0; j < o.tasks.size(); ++j) {
+                    td[j] = o.tasks[j];
+                    td[j].off += eb;
+                }
+                Placement *pl = places.data() + p_base[i];
+                for (size_t j = 0; j < o.places.size(); ++j) {
+                    pl[j] = o.places[j];
+                    pl[j].dst += eb;
+                }
+                HeaderRec *hd = p.headers.data() + h_base[i];
+                for (size_t j = 0; j < o.headers.size(); ++j) {
+                    hd[j] = o.headers[j];
+                    hd[j].dst += eb;
+                }
+                std::vector<TaskDesc>().swap(o.tasks);
+                std::vector<Placement>().swap(o.places);
+                std::vector<HeaderRec>().swap(o.headers);
+            }
+        };
+        std::vector<std::thread> pool;
+        const int nt = std::max(1, std::min(threads, NB));
+        for (int t = 0; t < nt; ++t) pool.emplace_back(copy);
+        for (auto &th : pool) th.join();
+    }
+    const uint64_t ebase = e_base[NB];
     p.n_entries = (long long)ebase;
+    lap("concatenate");
 }
 
 void plan_header(long long nnz, int m, int n, const PlanConfig &cfg, Plan &p)
@@ -533,7 +621,7 @@ void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cf
         for (auto &th : pool) th.join();
     }
 
-    std::vector<Placement> places;
+    PlaceVec places;
     finish_plan(block_visits, cfg, p, places, threads);
 
     // write the entries: a placement puts `len` consecutive sorted ratings into one lane-group

@@ -8,7 +8,10 @@
 #pragma once
 #include <cstdint>
 #include <functional>
+#include <memory>
+#include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace mfx {
@@ -39,6 +42,14 @@ struct HeaderRec { uint64_t dst; uint32_t own; uint32_t nch; uint32_t hot; uint3
 
 // "Put sorted ratings [src, src+len) into entries[dst + x*G], x = 0..len-1, the first one flagged."
 struct Placement { uint64_t src; uint64_t dst; uint32_t len; uint32_t pad; };
+// vector whose resize() leaves trivially constructible elements uninitialised: the merged placement list of a plan is
+// ~100 MB at 100 M ratings and is filled by several threads, which should also be the ones to touch its pages first
+template <class T> struct DefaultInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { typedef DefaultInitAlloc<U> other; };
+    template <class U> void construct(U *ptr) { ::new ((void *)ptr) U; }
+    template <class U, class... A> void construct(U *ptr, A &&...a) { ::new ((void *)ptr) U(std::forward<A>(a)...); }
+};
+typedef std::vector<Placement, DefaultInitAlloc<Placement>> PlaceVec;
 
 // Result of packing one block; entry offsets are relative to the block.
 struct BlockPack {
@@ -124,7 +135,7 @@ inline int stripe_of(const int *begin, int ns, unsigned id)
 void pack_visits(std::vector<Visit> &visits, int G, int target, int hot_len, BlockPack &out,
                  int one_task_waves = 0, const std::vector<int> *hot_slot_of_row = nullptr);
 void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig &cfg, Plan &p,
-                 std::vector<Placement> &places, int threads);
+                 PlaceVec &places, int threads);
 
 // number of floats per padded row: 8*ceil(k/8) (reference mf/mf.cpp:959)
 inline int k_aligned(int k) { return (k + 7) / 8 * 8; }

@@ -15,7 +15,12 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -290,6 +295,16 @@ void build_plan_device(const void *dR_v, long long nnz, int m, int n, const Plan
     int threads = cfg.threads > 0 ? cfg.threads : (int)std::thread::hardware_concurrency();
     if (threads < 1) threads = 1;
     const int NS = p.ns, NB = NS * NS, G = p.groups;
+    // MFX_PLAN_TIMING=1: wall time of every phase to stderr (each phase ends in a stream synchronise when it is on)
+    const bool timing = getenv("MFX_PLAN_TIMING") && atoi(getenv("MFX_PLAN_TIMING")) != 0;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "mfx plan: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
 
     // 1. statistics + id validation
     Buf<double> dSums;
@@ -323,8 +338,10 @@ void build_plan_device(const void *dR_v, long long nnz, int m, int n, const Plan
         p.std_dev = (float)std::sqrt(ex2 - ex * ex);
     }
     plan_scale(p);
+    lap("stats + counts");
     // id maps, stripe boundaries, omega (host: the glibc-compatible shuffle is serial)
     plan_maps(cfg, p, cnt_p.data(), cnt_q.data());
+    lap("id maps (host)");
 
     // 2. keys
     Buf<int> dPmap, dQmap, dBounds;
@@ -347,6 +364,7 @@ void build_plan_device(const void *dR_v, long long nnz, int m, int n, const Plan
     hipLaunchKernelGGL(key_build, dim3(grid_of(nnz, cu_count)), dim3(256), 0, s, dR, nnz, dPmap.p, dQmap.p,
                        p.owner_is_q ? 1 : 0, p.inv_scale, p.inv_scale != 1.0f ? 1 : 0, dBounds.p, NS, dKeyA.p, dValA.p);
 
+    lap("keys");
     // 3. sort by (block, owner, gathered); stable, so equal pairs keep their input order
     int blk_bits = 1;
     while ((1 << blk_bits) < NB) ++blk_bits;
@@ -357,6 +375,7 @@ void build_plan_device(const void *dR_v, long long nnz, int m, int n, const Plan
     dTmp.alloc(tmp_bytes);
     PREP_TRY(hipcub::DeviceRadixSort::SortPairs(dTmp.p, tmp_bytes, dKeyA.p, dKeyB.p, dValA.p, dValB.p, nnz, 0, end_bit, s));
 
+    lap("radix sort");
     // 4. visit table: run-length encode the (block | owner) part of the sorted keys
     if (nnz > 2147483647LL) throw std::invalid_argument("more than 2^31-1 ratings per trainer: shard the problem");
     Buf<int> dRunLen, dRuns; // run keys go to dKeyA (free after the sort)
@@ -377,21 +396,58 @@ void build_plan_device(const void *dR_v, long long nnz, int m, int n, const Plan
     PREP_TRY(hipMemcpyAsync(run_len.data(), dRunLen.p, (size_t)runs * 4, hipMemcpyDeviceToHost, s));
     PREP_TRY(hipStreamSynchronize(s));
 
+    lap("run-length encode + D2H");
     // 5. host: visits per block, packing into tasks (same code as the host builder)
     std::vector<std::vector<Visit>> block_visits(NB);
     {
-        std::vector<size_t> cnt(NB, 0);
-        for (int i = 0; i < runs; ++i) cnt[(size_t)(run_key[i] >> ID_BITS)]++;
-        for (int b = 0; b < NB; ++b) block_visits[b].reserve(cnt[b]);
-        uint64_t start = 0;
-        for (int i = 0; i < runs; ++i) {
-            const int b = (int)(run_key[i] >> ID_BITS);
-            block_visits[b].push_back({(uint32_t)(run_key[i] & ((1u << ID_BITS) - 1)), (uint32_t)run_len[i], start});
-            start += (uint64_t)run_len[i];
+        // the runs are sorted by block: every block is one range of them, filled by its own thread
+        std::vector<size_t> first((size_t)NB + 1, (size_t)runs);
+        for (int b = 0; b <= NB; ++b) {
+            const unsigned long long key = (unsigned long long)b << ID_BITS;
+            first[b] = (size_t)(std::lower_bound(run_key.begin(), run_key.end(), key) - run_key.begin());
+        }
+        std::vector<uint64_t> start_of((size_t)NB + 1, 0); // sorted position of a block's first rating
+        std::atomic<int> nb(0);
+        auto sum = [&]() {
+            for (;;) {
+                const int b = nb.fetch_add(1);
+                if (b >= NB) break;
+                uint64_t t = 0;
+                for (size_t i = first[b]; i < first[b + 1]; ++i) t += (uint64_t)run_len[i];
+                start_of[b + 1] = t;
+            }
+        };
+        auto fill = [&]() {
+            for (;;) {
+                const int b = nb.fetch_add(1);
+                if (b >= NB) break;
+                std::vector<Visit> &bv = block_visits[b];
+                bv.reserve(first[b + 1] - first[b]);
+                uint64_t start = start_of[b];
+                for (size_t i = first[b]; i < first[b + 1]; ++i) {
+                    bv.push_back({(uint32_t)(run_key[i] & ((1u << ID_BITS) - 1)), (uint32_t)run_len[i], start});
+                    start += (uint64_t)run_len[i];
+                }
+            }
+        };
+        const int nt = std::max(1, std::min(threads, NB));
+        {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nt; ++t) pool.emplace_back(sum);
+            for (auto &th : pool) th.join();
+        }
+        for (int b = 0; b < NB; ++b) start_of[b + 1] += start_of[b];
+        nb = 0;
+        {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nt; ++t) pool.emplace_back(fill);
+            for (auto &th : pool) th.join();
         }
     }
-    std::vector<Placement> places;
+    lap("visit table -> blocks (host)");
+    PlaceVec places;
     finish_plan(block_visits, cfg, p, places, threads);
+    lap("visits -> tasks (host)");
 
     // 6. entries on the device
     EntryD *dEntries = nullptr;
@@ -412,6 +468,7 @@ void build_plan_device(const void *dR_v, long long nnz, int m, int n, const Plan
         }
         PREP_TRY(hipGetLastError());
         PREP_TRY(hipStreamSynchronize(s));
+        lap("placements H2D + entries");
     } catch (...) {
         (void)hipFree(dEntries);
         throw;
