@@ -8,6 +8,7 @@ Python or CPU fallback: if the library or a GPU is missing the calls raise.
 """
 import ctypes as C
 import os
+import time
 
 import numpy as np
 
@@ -194,12 +195,16 @@ def synth_device(seed, first, count, m, n, dev_ptr, stream=None, shard=0):
 
 # ---- float-array facade (reference mf/mf.cpp:3483-3568) -----------------------------------
 
-def utility_train(train, p_l2=0.1, q_l2=0.1, k=8, iters=20, eta=0.1):
-    """mf::utility_train: float (u,v,r) triplets -> model array [fun,m,n,k,b,P,Q] or None."""
+def utility_train(train, p_l2=0.1, q_l2=0.1, k=8, iters=20, eta=0.1, timing=None):
+    """mf::utility_train: float (u,v,r) triplets -> model array [fun,m,n,k,b,P,Q] or None.
+    timing: a dict that receives "call_s", the wall time of the library call alone (without this wrapper's copy)."""
     t = np.ascontiguousarray(train, dtype=np.float32).ravel()
     lens = C.c_int(0)
+    t0 = time.perf_counter()
     p = getattr(lib(), MANGLED["utility_train"])(t.ctypes.data, len(t) // 3, p_l2, q_l2, k, iters,
                                                    eta, C.byref(lens))
+    if timing is not None:
+        timing["call_s"] = time.perf_counter() - t0
     if not p:
         return None
     out = np.ctypeslib.as_array(p, (lens.value,)).copy()

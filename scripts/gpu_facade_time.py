@@ -16,9 +16,11 @@ tri = np.empty(nnz * 3, dtype=np.float32)
 tri[0::3], tri[1::3], tri[2::3] = R["u"], R["v"], R["r"]
 for rep in range(2):
     t0 = time.time()
-    model = pkg.utility_train(tri, k=k, iters=iters)
+    tm = {}
+    model = pkg.utility_train(tri, k=k, iters=iters, timing=tm)
     t1 = time.time()
-    print("%s utility_train(%d triplets, k=%d, %d iters): %.3f s  (%d floats out)" % (name, nnz, k, iters, t1 - t0, len(model)), flush=True)
+    print("%s utility_train(%d triplets, k=%d, %d iters): library call %.3f s, with the wrapper's copy of the result %.3f s  (%d floats out)" %
+          (name, nnz, k, iters, tm["call_s"], t1 - t0, len(model)), flush=True)
     del model
 # the same in steps
 for rep in range(2):
