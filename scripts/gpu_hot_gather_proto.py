@@ -33,6 +33,8 @@ else:
     parts = [R]
 tr = []
 for i, Rp in enumerate(parts):
+    if i == 1 and os.environ.get("PROTO_HOT_LEN"):  # chain length of the hot pass alone (read when the plan is built)
+        os.environ["MFX_HOT_LEN"] = os.environ["PROTO_HOT_LEN"]
     opts = pkg.default_options(k=k, use_stats=1, stats_avg=avg, stats_std=std, owner_side=(2 if i == 0 else 1), stripes=NS)
     tr.append(pkg.Trainer(Rp, m, n, opts=opts, layout_counts=(cnt_p, cnt_q)))
 maps = [t.maps() for t in tr]
