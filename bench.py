@@ -247,7 +247,8 @@ def main():
     ap.add_argument("--same-device", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--combine", default=os.environ.get("MFX_COMBINE", "rotate"),
                     help="how the item factors Q are shared when N>1: rotate (item slots travel round the ring of "
-                         "ranks, one writer per row: exact SGD) | avg (replicas averaged by all-reduce)")
+                         "ranks, one writer per row: exact SGD) | avg (replicas averaged by all-reduce) | wavg (the same, every "
+                         "item row weighted by the number of ratings the rank holds for it: SURVEY.md 8e's count-weighted reduce)")
     ap.add_argument("--slots-per-rank", type=int, default=int(os.environ.get("MFX_SLOTS_PER_RANK", "0")),
                     help="rotate: item slots per rank (2 = the ring transfer runs under the next step's kernels, 1 = fewer "
                          "passes over the user factors, transfer exposed; 0 = auto: 2 up to 4 GPUs, 1 beyond)")
@@ -377,7 +378,6 @@ def main():
         opts = pkg.default_options(k=k, lambda_p2=HYPER["lambda_p"], lambda_q2=HYPER["lambda_q"], eta=HYPER["eta"],
                                    device=local_rank, identity_maps=2)
         t = pkg.Trainer(None, m, n, opts=opts, device_ptr=R_dev.data_ptr(), nnz=nnz)
-        del R_dev
         info = t.info
         ka = info.k_aligned
         # factors live in torch tensors so RCCL can reduce them in place
@@ -388,12 +388,34 @@ def main():
         t.bind_model(P.data_ptr(), Q.data_ptr(), PG.data_ptr(), QG.data_ptr())
         t.init_model()  # same seed stream on every rank: Q starts identical everywhere
         nsync = max(1, min(args.syncs_per_epoch, info.stripes))
+        w_rows = None
+        if args.combine == "wavg":
+            # weight of this rank's copy of an item row = its share of the item's ratings (rows in the internal layout)
+            Rv = R_dev.view(-1, 3)[:, 1].long()
+            cnt = torch.bincount(Rv, minlength=n).double()
+            tot = cnt.clone() if args.backend == "nccl" else cnt.cpu()
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            tot = tot.to(dev)
+            w = torch.where(tot > 0, cnt / tot.clamp(min=1.0), torch.full_like(cnt, 1.0 / world)).float()
+            q_map = torch.from_numpy(t.maps()[1].astype(np.int64)).to(dev)
+            w_rows = torch.empty(n, dtype=torch.float32, device=dev)
+            w_rows[q_map] = w  # original item id -> row of Q
+            del Rv, cnt, tot, w, q_map
+        del R_dev
 
         def average_q():
             """--combine avg: replicated item factors, Q <- mean over ranks (summing the replicas' deltas
             instead diverges -- profiles/experiments/r01_deltasum_4rank_rehearsal.log)."""
             for x in (Q, QG):
-                if args.backend == "nccl":
+                if w_rows is not None:  # count-weighted mean: scale this rank's rows by its weight, then sum
+                    x.view(n, -1).mul_(w_rows[:, None])
+                    if args.backend == "nccl":
+                        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+                    else:
+                        h = x.cpu()
+                        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                        x.copy_(h)
+                elif args.backend == "nccl":
                     dist.all_reduce(x, op=dist.ReduceOp.AVG)  # RCCL over xGMI
                 else:  # rehearsal path (gloo): stage through the host
                     h = x.cpu()

@@ -12,8 +12,9 @@ factors Q over RCCL (torch.distributed backend "nccl" on ROCm; "gloo" in the CPU
           (default beyond 4 ranks: fewer, larger slot trainers) is the plain "train, then shift" ring
           (auto_slots_per_rank).
   avg     -- Q replicated, all-reduce mean after each (part of an) epoch, as BASELINE.json words it.
-          Measured to lose the fit (4 ranks, 20 epochs: RMSE 0.97 vs 0.72): the replicas' latent
-          bases drift apart between averaging points.  Kept selectable for comparison.
+          Measured to lose the fit (4 ranks x configs[1], 20 epochs: RMSE 0.758, count-weighted 0.755, against 0.653 by
+          rotation and 0.658 by the oracle on the union problem): the replicas' latent bases drift apart between
+          averaging points.  Kept selectable for comparison (bench.py --combine avg | wavg).
 
 Only tensor bookkeeping lives here -- the SGD itself is the HIP kernel behind mfx_trainer_epoch.
 """
