@@ -19,6 +19,8 @@ R = pkg.synth_host(g["seed"], 0, nnz, m, n)
 dev = torch.device("cuda", 0)
 torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 stream = torch.cuda.current_stream().cuda_stream
+CONCURRENT = os.environ.get("PROTO_CONCURRENT", "0") != "0"
+s1, s2 = torch.cuda.current_stream(), torch.cuda.Stream(device=dev)
 cnt_p = np.bincount(R["u"], minlength=m).astype(np.int32)
 cnt_q = np.bincount(R["v"], minlength=n).astype(np.int32)
 r64 = R["r"].astype(np.float64)
@@ -49,6 +51,15 @@ vals, ms = [], []
 for _ in range(runs):
     for t in tr: t.init_model_counts(cnt_p, cnt_q)  # (the same values, written once per trainer)
     def epoch(slow):
+        if len(tr) == 2 and CONCURRENT:
+            # both passes of a round at the same time on two streams (they meet in the XCD's L2); a round starts when
+            # both passes of the round before it are done
+            for r in range(NS):
+                s2.wait_stream(s1)
+                tr[0].epoch_part(r, NS, slow_only=slow, stream=s1.cuda_stream)
+                tr[1].epoch_part(r, NS, slow_only=slow, stream=s2.cuda_stream)
+                s1.wait_stream(s2)
+            return
         for r in range(NS):
             for t in tr:
                 t.epoch_part(r, NS, slow_only=slow, stream=stream)
