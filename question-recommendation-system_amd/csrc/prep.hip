@@ -361,6 +361,7 @@ void build_plan_device(const void *dR_v, long long nnz, int m, int n, const Plan
     dKeyB.alloc(nnz);
     dValA.alloc(nnz);
     dValB.alloc(nnz);
+    lap("maps H2D + key buffers");
     hipLaunchKernelGGL(key_build, dim3(grid_of(nnz, cu_count)), dim3(256), 0, s, dR, nnz, dPmap.p, dQmap.p,
                        p.owner_is_q ? 1 : 0, p.inv_scale, p.inv_scale != 1.0f ? 1 : 0, dBounds.p, NS, dKeyA.p, dValA.p);
 
@@ -373,6 +374,7 @@ void build_plan_device(const void *dR_v, long long nnz, int m, int n, const Plan
     PREP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, dKeyA.p, dKeyB.p, dValA.p, dValB.p, nnz, 0, end_bit, s));
     Buf<char> dTmp;
     dTmp.alloc(tmp_bytes);
+    lap("sort scratch");
     PREP_TRY(hipcub::DeviceRadixSort::SortPairs(dTmp.p, tmp_bytes, dKeyA.p, dKeyB.p, dValA.p, dValB.p, nnz, 0, end_bit, s));
 
     lap("radix sort");

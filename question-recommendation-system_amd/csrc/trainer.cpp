@@ -6,6 +6,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -301,6 +302,13 @@ static int create_impl(const mfx::Node *R, const void *R_dev, long long nnz, int
     // or the ids do not fit the sort key.  R may be host memory (uploaded once) or already in HBM.
     const bool device_plan = env_int("MFX_HOST_PLAN", 0) == 0 && mfx::device_prep_supported(m, n);
     mfx::EntryD *dev_entries = nullptr;
+    const bool plan_timing = env_int("MFX_PLAN_TIMING", 0) != 0;
+    const auto t_create = std::chrono::steady_clock::now();
+    auto since = [&](const char *what) {
+        if (plan_timing)
+            fprintf(stderr, "mfx create: %-26s %8.2f ms since the start\n", what,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count());
+    };
     try {
         if (device_plan) {
             hipStream_t ps = nullptr;
@@ -341,6 +349,7 @@ static int create_impl(const mfx::Node *R, const void *R_dev, long long nnz, int
         delete t;
         return fail(MFX_E_HIP, e.what());
     }
+    since("plan built, scratch freed");
     mfx::Plan &p = t->plan;
     t->lambda_p = opt.lambda_p2 / p.scale;
     t->lambda_q = opt.lambda_q2 / p.scale;
@@ -412,6 +421,7 @@ static int create_impl(const mfx::Node *R, const void *R_dev, long long nnz, int
     }
     std::vector<mfx::Entry>().swap(p.entries);
     std::vector<mfx::TaskDesc>().swap(p.tasks);
+    since("plan tables on the device");
     *out = t;
     return MFX_OK;
 }
