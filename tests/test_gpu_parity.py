@@ -269,7 +269,7 @@ def test_stripe_rotation_one_rank_is_plain_sgd(pkg, orc, world):
     assert abs(got - want) / want < RMSE_RTOL, (got, want)
 
 
-@pytest.mark.parametrize("epochs", [8, 12])
+@pytest.mark.parametrize("epochs", [8, 12, 20])  # 20 = the facade's default (mf_get_default_param)
 def test_config2_full_size(pkg, epochs):
     """BASELINE configs[2]: 1M x 500k, 100M ratings, k=64 (model 384 MB, beyond the L2s), the bench workload.  The
     oracle needs minutes for this; its results on these exact triples are fixtures (tests/golden/full_size.json,
