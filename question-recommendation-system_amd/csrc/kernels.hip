@@ -141,6 +141,11 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
     __shared__ u4 ering_all[4][2 * EBLK]; // per wave: a ring of two blocks, 16-byte slots
     u4 *const ering = ering_all[threadIdx.x >> 6];
     __shared__ int wg_first;
+#ifdef MFX_OWNER_LDS
+    // experiment (make variant VFLAGS=-DMFX_OWNER_LDS): the "LDS-staged latent tile" for the one side that has re-use -- the
+    // owner row of a visit lives in LDS (read before and written after every update) instead of in registers
+    __shared__ volatile f4 own_tile[256];
+#endif
     const int lane = threadIdx.x & 63;
     const int lig = lane % LANES;
     const int grp = lane / LANES;
@@ -327,6 +332,9 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                 // (A slot is HOT_SUB partial sums: hundreds of chains of one row adding to the same words would
                 //  queue at one memory channel, ~12 ns per wave instruction -- 47 us for the head row of configs[1].)
                 auto close_visit = [&]() {
+#ifdef MFX_OWNER_LDS
+                    o = own_tile[threadIdx.x];
+#endif
                     if (hot_n == 0) {
                         if (lane_ok) *(f4 *)(a.own_rows + (size_t)cur * ka + d0) = o;
                         if (lig == 0) *(f2 *)(a.own_acc + (size_t)cur * 2) = f2{og0, og1};
@@ -369,6 +377,9 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                             ogn = ld_acc(a.own_acc + (size_t)id * 2);
                         }
                         o = on;
+#ifdef MFX_OWNER_LDS
+                        own_tile[threadIdx.x] = o; // experiment: the owner row of the visit staged in LDS, not held in registers
+#endif
                         og0 = ogn.x;
                         og1 = ogn.y;
                         o_start = on; // (what a hot chain's change is measured against)
@@ -404,6 +415,9 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     STAMP(ts1);
                     // ---- compute: z = p.q (calc_z), err = r - z (prepare_for_sg_update) ----
                     // (written on float pairs: one v_pk_* instruction per two factors)
+#ifdef MFX_OWNER_LDS
+                    o = own_tile[threadIdx.x];
+#endif
                     f2 o01 = {o.x, o.y}, o23 = {o.z, o.w}, g01 = {g.x, g.y}, g23 = {g.z, g.w};
                     const f2 zz = o01 * g01 + o23 * g23;
                     const float z = group_sum<LANES>(zz.x + zz.y);
@@ -427,6 +441,9 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                         g23 -= eta_g * gq23;
                         o = f4{o01.x, o01.y, o23.x, o23.y};
                         g = f4{g01.x, g01.y, g23.x, g23.y};
+#ifdef MFX_OWNER_LDS
+                        own_tile[threadIdx.x] = o;
+#endif
                     }
                     // ---- one burst of memory operations ----
                     const bool nact = enext.gat >= 0 && step + 1 < nsteps;
