@@ -292,13 +292,16 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
         t_last = now;
     };
     // Tasks per wave.  A block is cut into (tasks per wave) x (waves of its XCD) tasks of equal load
-    // (longest-first packing), handed out through the block's cursor.  One task per wave when a wave's
-    // share of the launch is short -- every hand-over costs a chain of misses -- and two when it is long,
-    // so that the waves that run ahead take up the slack (measured: profiles/experiments/r01_task_sweep*.log).
+    // (longest-first packing), handed out through the block's cursor.  One task per wave -- every hand-over costs a
+    // chain of misses, and longer lists keep the order closer to the reference's walk through a block (final RMSE
+    // 0.4 .. 0.6 points closer to the oracle on configs[1] and configs[2] at no cost in time,
+    // profiles/experiments/r02_tasks_per_wave.log) -- except for wide rows (k_a >= 128: two ratings per wave step) with a
+    // long share per wave, where two tasks let the waves that run ahead take up the slack (3 .. 15 % of the epoch time;
+    // round 1: profiles/experiments/r01_task_sweep*.log).
     // MFX_ONE_TASK=0 selects the older graded sizes (T, T/2, T/4, T/8 from task_steps).
     const long long per_wave = p.nnz / ((long long)NB * G * std::max(1, cfg.waves_per_stripe));
     const char *ot = getenv("MFX_ONE_TASK");
-    const int tasks_per_wave = ot && *ot ? atoi(ot) : cfg.task_steps > 0 ? 0 : per_wave < 128 ? 1 : 2;
+    const int tasks_per_wave = ot && *ot ? atoi(ot) : cfg.task_steps > 0 ? 0 : (per_wave < 128 || G >= 4) ? 1 : 2;
     const int one_task = tasks_per_wave * std::max(1, cfg.waves_per_stripe);
     // combine slots: one per owner row that is cut into chains in some block (row -> slot, -1 = none)
     std::vector<int> hot_slot((size_t)(p.owner_is_q ? p.n : p.m), -1);
