@@ -202,8 +202,8 @@ def test_other_epoch_counts_and_the_bench_sample(pkg, name, epochs):
     """The facade's default is 20 iterations (reference mf/mf.cpp:4546): configs[1] after 20 epochs, where a damping of the hot
     rows that is tuned at 12 epochs shows (it read +4.1 % before the lists stopped running their heavy rows first); and the
     20 M-rating sample of configs[2] that bench.py times the CPU reference on.  The lock-free path is not deterministic: at
-    20 epochs single runs of configs[1] spread +-0.5 % (observed +2.0 .. +3.2 %), so the MEDIAN of three runs is held to the
-    tolerance."""
+    20 epochs single runs of configs[1] spread +-0.8 % (30 runs: +1.4 .. +3.1 %, median +2.0 %, one beyond 3 %;
+    profiles/experiments/r02_tasks_per_wave.log), so the MEDIAN of five runs is held to the tolerance."""
     import torch
     g = FULL[name]
     m, n, nnz, k = g["m"], g["n"], g["nnz"], g["k"]
@@ -211,14 +211,16 @@ def test_other_epoch_counts_and_the_bench_sample(pkg, name, epochs):
     pkg.synth_device(g["seed"], 0, nnz, m, n, R.data_ptr(), None, shard=0)
     torch.cuda.synchronize()
     got = []
-    for _ in range(3):
-        t = pkg.Trainer(None, m, n, opts=pkg.default_options(k=k), device_ptr=R.data_ptr(), nnz=nnz); t.init_model()
+    t = pkg.Trainer(None, m, n, opts=pkg.default_options(k=k), device_ptr=R.data_ptr(), nnz=nnz)
+    for _ in range(5):
+        t.init_model()
         t.train(epochs)
-        got.append(t.rmse()); t.close()
+        got.append(t.rmse())
+    t.close()
     want = g["rmse_after"][str(epochs)]
     rm = float(np.median(got))
     assert abs(rm - want) / want < RMSE_RTOL, (got, want)
-    assert max(got) - min(got) < 0.015 * want, got  # run-to-run spread stays small
+    assert max(got) - min(got) < 0.025 * want, got  # run-to-run spread stays small (30 runs of configs[1]: 1.7 % from end to end)
 
 
 def test_slow_only_epoch_touches_first_eight_factors(pkg):
