@@ -69,7 +69,7 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
     const int study_dump_minn = getenv("ORC_STUDY_DUMP_MINN") ? atoi(getenv("ORC_STUDY_DUMP_MINN")) : 0;
     int dumped = 0;
     const double study_blend = getenv("ORC_STUDY_BLEND") ? atof(getenv("ORC_STUDY_BLEND")) : 0.0;
-    const double study_smul = getenv("ORC_STUDY_SMUL") ? atof(getenv("ORC_STUDY_SMUL")) : 1.0; /* = HOT_S_GAIN of kernels.hpp */
+    const double study_smul = getenv("ORC_STUDY_SMUL") ? atof(getenv("ORC_STUDY_SMUL")) : 0.7; /* = HOT_S_GAIN of kernels.hpp */
     const double study_rgain = getenv("ORC_STUDY_RGAIN") ? atof(getenv("ORC_STUDY_RGAIN")) : 1.0;
     const int study_nform = getenv("ORC_STUDY_NFORM") ? atoi(getenv("ORC_STUDY_NFORM")) : 2; /* as the kernel: gain * (n / n0 + 1)^npow */
     const double study_n0 = getenv("ORC_STUDY_N0") ? atof(getenv("ORC_STUDY_N0")) : 2.0; /* = HOT_S_N0 of kernels.hpp */

@@ -11,7 +11,7 @@ struct TaskDescD { uint64_t off; uint32_t nsteps; uint32_t pad; };
 
 constexpr int LOSS_SLOTS = 256; // the epoch loss is kept as this many partial sums
 constexpr int HOT_SUB = 8;      // a hot row's combine slot is kept as this many partial sums of (ka + HOT_EXTRA) floats:
-constexpr float HOT_S_GAIN = 1.0f; // fold_hot_rows: gain on the contraction estimate (calibrated, see there)
+constexpr float HOT_S_GAIN = 0.7f; // fold_hot_rows: gain on the contraction estimate (calibrated, see there)
 constexpr float HOT_S_N0 = 2.0f;   // > 0: the gain grows with the chain count, g * (n / n0 + 1)^HOT_S_POW
 constexpr float HOT_S_POW = 0.5f;
 constexpr int HOT_EXTRA = 5;    // the row, then both accumulator slots, squared errors, ratings, chains

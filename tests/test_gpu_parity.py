@@ -202,8 +202,8 @@ def test_other_epoch_counts_and_the_bench_sample(pkg, name, epochs):
     """The facade's default is 20 iterations (reference mf/mf.cpp:4546): configs[1] after 20 epochs, where a damping of the hot
     rows that is tuned at 12 epochs shows (it read +4.1 % before the lists stopped running their heavy rows first); and the
     20 M-rating sample of configs[2] that bench.py times the CPU reference on.  The lock-free path is not deterministic: at
-    20 epochs single runs of configs[1] spread +-0.8 % (30 runs: +1.4 .. +3.1 %, median +2.0 %, one beyond 3 %;
-    profiles/experiments/r02_tasks_per_wave.log), so the MEDIAN of five runs is held to the tolerance."""
+    20 epochs single runs of configs[1] spread +-0.8 % (30 runs: +0.9 .. +2.5 %, median +1.7 %;
+    profiles/experiments/r02_fold_gain_shape.log), so the MEDIAN of five runs is held to the tolerance."""
     import torch
     g = FULL[name]
     m, n, nnz, k = g["m"], g["n"], g["nnz"], g["k"]
