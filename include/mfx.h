@@ -44,7 +44,8 @@ typedef struct mfx_options {
     int stripes;       /* stripe count per side = launches per epoch; 0 = one per XCD  */
     int wg_per_cu;     /* resident 256-thread workgroups per CU; 0 = auto              */
     int task_steps;    /* ratings per lane-group per task; 0 = auto                    */
-    int reserved0;     /* unused (was an experiment knob); keep 0                      */
+    int swap_heavy;    /* 1 (experimental): the heavy rows of the GATHERED side also run in workgroup tasks, with the
+                          roles swapped, instead of staying on the lock-free side (default 0; DESIGN.md "Heavy rows") */
     int rk_mode;       /* 0: 1/8 for both accumulator slots (SSE build as shipped,
                           mf.cpp:1233-1234); 1: 1/(k_a-8) for slot 1 (mf.cpp:1314-1315) */
     int owner_side;    /* 0 auto (side with fewer rows), 1 users (P), 2 items (Q)      */
@@ -67,10 +68,14 @@ typedef struct mfx_info {
     int owner_is_q;
     long long n_entries;             /* nnz + padding slots                              */
     long long n_tasks;
-    long long n_hot_rows;
+    long long n_hot_rows;            /* visits of heavy rows (workgroup visits)          */
     int cu_count, xcd_count, wg_per_cu;
     void *dP, *dQ, *dPG, *dQG;       /* device pointers (internal ids, k_aligned stride) */
     double bytes_per_rating;         /* algorithmic: 16*k_aligned + 44    */
+    long long n_wg_tasks, n_wg_visits; /* workgroup tasks (heavy rows) and their visits  */
+    long long n_hot_slots;           /* rows split over several workgroups somewhere     */
+    long long hot_acc_bytes;         /* HBM held by their combine slots                  */
+    int waves_per_wg, hot_len;       /* waves of a workgroup that take work; a row with more ratings in a block is heavy */
 } mfx_info;
 
 int mfx_abi_version(void);
@@ -139,6 +144,8 @@ int mfx_trainer_info(mfx_trainer *t, mfx_info *info);
 int mfx_trainer_maps(mfx_trainer *t, int *p_map, int *q_map);
 /* the stripe/task layout as it sits in HBM (tests): n_entries*12 B, n_tasks*16 B, stripes^2+1 longs */
 int mfx_trainer_plan_copy(mfx_trainer *t, void *entries, void *tasks, long long *slot_task_ptr);
+/* ... and its workgroup tasks: n_wg_tasks*24 B, n_wg_visits*24 B, stripes^2+1 longs (mfx_plan_view says what they hold) */
+int mfx_trainer_plan_copy_wg(mfx_trainer *t, void *wg_tasks, void *wg_visits, long long *slot_wg_ptr);
 /* raw factors in internal layout, for tests and checkpoints */
 int mfx_trainer_get_model(mfx_trainer *t, float *P, float *Q, float *PG, float *QG);
 int mfx_trainer_set_model(mfx_trainer *t, const float *P, const float *Q, const float *PG,
@@ -165,10 +172,12 @@ int mfx_trainer_export(mfx_trainer *t, float *model_arr, long long len);
  * device: pairs = (u,v) as floats, out = float[npairs].  Host buffers. */
 int mfx_predict_array(const float *model_arr, long long model_len, const float *pairs,
                       long long npairs, float *out);
-/* The model array of the last mfx_predict_array / mfx_rmse_array call stays resident in HBM (the reference's
- * array_to_model copies the whole model per call, mf.cpp:3444-3481, 3537-3568): a call with the same host
- * pointer, length, header and sampled checksum skips the upload.  _drop releases it (call it after changing an
- * array in place); _stats counts uploads and hits since process start.  MFX_PREDICT_CACHE=0 disables the reuse. */
+/* By default the model array is uploaded on every call, like the reference's array_to_model (mf.cpp:3444-3481).
+ * mfx_predict_cache_enable(1) (or MFX_PREDICT_CACHE=1 in the environment) keeps the array of the last
+ * mfx_predict_array / mfx_rmse_array call resident in HBM: a call with the same host pointer, length, header and
+ * sampled checksum then skips the upload.  The checksum reads 16 K words, not all of them: a caller that enables the
+ * reuse must call mfx_predict_cache_drop() after changing an array in place.  _stats counts uploads and hits. */
+void mfx_predict_cache_enable(int on);
 void mfx_predict_cache_drop(void);
 void mfx_predict_cache_stats(long long *uploads, long long *hits);
 /* calc_rmse (mf.cpp:4316-4331) of a facade array on host ratings, on the device. */
@@ -188,7 +197,16 @@ typedef struct mfx_plan_view {
     const void *tasks;              /* {uint64 entry_off, uint32 nsteps, uint32 pad}            */
     const long long *slot_task_ptr; /* stripes*stripes+1, ordered (round, slot)                */
     const int *p_begin, *q_begin;   /* stripes+1 internal-id boundaries of the user / item stripes */
-    long long n_hot_slots;          /* owner rows that are cut into chains somewhere (combine slots of the kernel) */
+    long long n_hot_slots;          /* rows that are split over several workgroups somewhere (combine slots of the kernel) */
+    /* workgroup tasks: the heavy rows (more than hot_len ratings in a block, either side).  A task = nvisits visits run one
+     * after the other by the waves_per_wg x ratings_per_wave lists of ONE workgroup on one LDS copy of the row; its entries
+     * are stored wave-major (wave w: [off + w*nsteps*G, off + (w+1)*nsteps*G), step-major inside).                        */
+    const void *wg_tasks;           /* {uint64 off, uint32 nsteps, visit0, nvisits, swapped}                              */
+    const void *wg_visits;          /* {uint32 row, nsteps, len, info = copies << 1 | swapped, slot, pad}                 */
+    const long long *slot_wg_ptr;   /* stripes*stripes+1, ordered (round, slot)                                           */
+    long long n_wg_tasks, n_wg_visits;
+    int waves_per_wg, hot_len;
+    const int *hot_rows;            /* combine slot -> internal row | side << 31 (1 = the plan's gathered side)           */
 } mfx_plan_view;
 int mfx_hostplan_build(const mfx_node *R_host, long long nnz, int m, int n,
                        const mfx_options *opt, mfx_hostplan **out);

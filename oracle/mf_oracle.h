@@ -59,9 +59,10 @@ typedef struct {
 int orc_train_order(const orc_node *R, long long nnz, int m, int n, const orc_param *prm,
                     orc_model *out, double *tr_rmse, double *obj, const orc_order *ord);
 /* plan_order.c: orc_sgd_one over the GPU plan's own entry stream (see the header of that file) */
-int orc_plan_order_train(const void *entries, const void *tasks, const long long *slot_task_ptr, int ns, int G,
+int orc_plan_order_train(const void *entries, const void *tasks, const long long *slot_task_ptr, const void *wg_tasks,
+                         const void *wg_visits, const long long *slot_wg_ptr, const unsigned *hot_rows, int ns, int G, int W,
                          int ka, int owner_is_q, float *P, float *Q, float *PG, float *QG, long long n_hot_slots,
-                         float lambda_p, float lambda_q, float eta, int epochs, int first_epoch, int chain_mode,
+                         float lambda_p, float lambda_q, float eta, int epochs, int first_epoch, int mode,
                          int rsqrt_mode, int rk_mode, double *epoch_loss);
 void orc_free_model(orc_model *mdl);
 

@@ -50,8 +50,8 @@ def lib():
         vp, ll, i32, f32 = C.c_void_p, C.c_longlong, C.c_int, C.c_float
         L.orc_train.argtypes = [vp, ll, i32, i32, C.POINTER(Param), C.POINTER(Model), vp, vp]
         L.orc_train_order.argtypes = [vp, ll, i32, i32, C.POINTER(Param), C.POINTER(Model), vp, vp, C.POINTER(Order)]
-        L.orc_plan_order_train.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, ll, f32, f32, f32, i32, i32,
-                                           i32, i32, i32, vp]
+        L.orc_plan_order_train.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, ll, f32, f32, f32,
+                                           i32, i32, i32, i32, i32, vp]
         L.orc_rmse.restype = C.c_double
         L.orc_rmse.argtypes = [vp, ll, C.POINTER(Model)]
         L.orc_predict.restype = f32
@@ -142,10 +142,30 @@ def train(R, m, n, k=8, iters=20, bins=20, lambda_p=0.1, lambda_q=0.1, eta=0.1,
     return (arr, tr, ob) if progress else arr
 
 
-CHAIN_LAST_WINS, CHAIN_FOLD, CHAIN_SHARED = 0, 1, 2
+HEAVY_AS_KERNEL, HEAVY_IN_PLACE, HEAVY_MEAN = 1, 2, 3  # plan_order.c: what happens to the heavy rows (workgroup visits)
+CHAIN_FOLD, CHAIN_SHARED = HEAVY_AS_KERNEL, HEAVY_IN_PLACE  # (names of rounds 1-2)
 
 
-def plan_order_train(hp, epochs, lambda_p=0.1, lambda_q=0.1, eta=0.1, chain_mode=CHAIN_FOLD,
+def plan_order_run(hp, P, Q, PG, QG, epochs, lambda_p=0.1, lambda_q=0.1, eta=0.1, mode=HEAVY_AS_KERNEL, first_epoch=0,
+                   rsqrt_mode=RSQRT_EXACT, rk_mode=RK_AS_BUILT):
+    """orc_plan_order_train on caller-owned factors (internal ids, padded width), in place.  Returns the per-epoch
+    sums of squared errors (scaled units)."""
+    v = hp.view
+    loss = np.zeros(epochs)
+    scale = np.float32(v.scale)
+    keep = [np.ascontiguousarray(x) for x in (hp.entries, hp.tasks, hp.slot_task_ptr, hp.wg_tasks, hp.wg_visits, hp.slot_wg_ptr,
+                                              hp.hot_rows)]
+    ptr = [x.ctypes.data if len(x) else None for x in keep]
+    rc = lib().orc_plan_order_train(ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], ptr[5], ptr[6], v.stripes, v.ratings_per_wave,
+                                    v.waves_per_wg, v.k_aligned, v.owner_is_q, P.ctypes.data, Q.ctypes.data, PG.ctypes.data,
+                                    QG.ctypes.data, v.n_hot_slots, np.float32(lambda_p) / scale, np.float32(lambda_q) / scale, eta,
+                                    epochs, first_epoch, mode, rsqrt_mode, rk_mode, loss.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("orc_plan_order_train failed: %d" % rc)
+    return loss
+
+
+def plan_order_train(hp, epochs, lambda_p=0.1, lambda_q=0.1, eta=0.1, chain_mode=HEAVY_AS_KERNEL,
                      rsqrt_mode=RSQRT_EXACT, rk_mode=RK_AS_BUILT):
     """The oracle's update (orc_sgd_one) applied in the order of a GPU plan (`hp`: the package's HostPlan).
     Returns (facade array [fun,m,n,k,b,P,Q] in original ids, per-epoch online tr_rmse) -- what the GPU trainer
@@ -154,15 +174,8 @@ def plan_order_train(hp, epochs, lambda_p=0.1, lambda_q=0.1, eta=0.1, chain_mode
     P, Q = hp.init_factors()
     PG = np.ones((v.m, 2), dtype=np.float32)
     QG = np.ones((v.n, 2), dtype=np.float32)
-    loss = np.zeros(epochs)
     scale = np.float32(v.scale)
-    ent, tsk, sp = np.ascontiguousarray(hp.entries), np.ascontiguousarray(hp.tasks), np.ascontiguousarray(hp.slot_task_ptr)
-    rc = lib().orc_plan_order_train(ent.ctypes.data, tsk.ctypes.data, sp.ctypes.data, v.stripes, v.ratings_per_wave,
-                                    v.k_aligned, v.owner_is_q, P.ctypes.data, Q.ctypes.data, PG.ctypes.data, QG.ctypes.data,
-                                    v.n_hot_slots, np.float32(lambda_p) / scale, np.float32(lambda_q) / scale, eta, epochs, 0,
-                                    chain_mode, rsqrt_mode, rk_mode, loss.ctypes.data)
-    if rc != 0:
-        raise RuntimeError("orc_plan_order_train failed: %d" % rc)
+    loss = plan_order_run(hp, P, Q, PG, QG, epochs, lambda_p, lambda_q, eta, chain_mode, 0, rsqrt_mode, rk_mode)
     # export like the trainer: scale_model, shrink_model, shuffle_model (reference mf/mf.cpp:529-553, 1057-1074, 1027-1055)
     f = np.float32(np.sqrt(scale)) if scale != 1.0 else np.float32(1.0)
     Po = P[hp.p_map][:, :v.k] * f

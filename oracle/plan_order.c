@@ -3,24 +3,23 @@
  *
  * The GPU trainer visits the ratings in another order than the reference (stripe rounds instead of the
  * block scheduler of reference mf/mf.cpp:49-312; the lists of a block advance side by side instead of one
- * thread walking a sorted block, mf.cpp:1201-1238; a heavy owner row is cut into chains).  SGD is order
- * dependent, so a difference in final RMSE between the GPU path and orc_train mixes two things: arithmetic
- * and order.  This file separates them: it walks the plan's own entry stream (mfx_plan_view: entries, tasks,
- * slot_task_ptr) on one CPU thread -- rounds in the kernel's order, the lists of a block in lock step, owner
- * rows held in a private copy for the length of a visit exactly as the kernel holds them in registers -- with
- * the oracle's update.  What is left between this and the GPU is the lock-free execution itself.
+ * thread walking a sorted block, mf.cpp:1201-1238; a heavy row's ratings are dealt over all lists of one
+ * workgroup).  SGD is order dependent, so a difference in final RMSE between the GPU path and orc_train
+ * mixes two things: arithmetic and order.  This file separates them: it walks the plan's own entry stream
+ * (mfx_plan_view: entries, wave tasks, workgroup tasks and their visits) on one CPU thread -- rounds in the
+ * kernel's order, every list of a block in lock step, owner rows of the wave tasks held in a private copy for
+ * the length of a visit exactly as the kernel holds them in registers, the heavy row of a workgroup visit in
+ * ONE copy that all lists of the workgroup add to, exactly as the kernel keeps it in LDS -- with the oracle's
+ * update.  What is left between this and the GPU is the lock-free execution itself.
  *
- * chain_mode says what happens to an owner row that the plan cut into chains:
- *   0  every chain works on a private copy, the last one to end overwrites the row (round 1's kernel)
- *   1  private copies, folded when the last chain of the launch ends (kernels.hip "hot chains", same formula)
- *   2  no private copies for chains: every chain updates the row in memory at once (what one thread walking the
- *      interleaved lists would do -- the sequential meaning of this order)
- *   6  (study) private copies; chain number idx of a row starts with its accumulators advanced by idx x the growth one
- *      chain of that row showed at the row's fold before (so the step sizes along the visit fall as they would
- *      sequentially); summed change damped as in mode 1 without the step-size ratio
- *   3  private copies; every chain's change is weighted by what a sequential pass would have left of it -- the
- *      step-size ratio of its place in the visit and exp(-contraction of the chains behind it) -- and the weighted
- *      changes are summed
+ * mode says what happens to the heavy rows (workgroup visits):
+ *   1  as the kernel: one copy per workgroup visit, every wave of the workgroup reads it once per step and its G
+ *      lists add what they change; a row split over several workgroups is folded with fold_hot_rows' formula
+ *   2  the sequential meaning of the order: every rating of a heavy row updates the row in memory at once, and the G lists
+ *      of a wave take their turn one after the other (modes 1 and 3: one step of a wave is one burst of loads followed by
+ *      one burst of stores, as on the GPU)
+ *   3  (study) as 1, but a split row becomes the MEAN of its copies
+ *   4  (study) as 1, but every rating sees the copy as the rating before it left it (no W x G ratings in flight)
  */
 #include <math.h>
 #include <stdint.h>
@@ -32,57 +31,56 @@
 
 typedef struct { uint32_t own; int32_t gat; float r; } pl_entry;
 typedef struct { uint64_t off; uint32_t nsteps; uint32_t pad; } pl_task;
+typedef struct { uint64_t off; uint32_t nsteps; uint32_t visit0; uint32_t nvisits; uint32_t swapped; } pl_wgtask;
+typedef struct { uint32_t row; uint32_t nsteps; uint32_t len; uint32_t info; uint32_t slot; uint32_t pad; } pl_wgvisit;
+
+#define IDMASK 0x3FFFFFFFu
 
 typedef struct {
-    uint32_t cur;      /* owner row of the visit in progress, 0xFFFFFFFF = none */
-    int hot_n;         /* > 0: the visit is one of hot_n chains */
-    uint32_t hot_h;    /* combine slot | chain length << 20 */
-    float e0;          /* list's squared-error sum when the chain began */
-    float tsum;
+    uint32_t cur; /* owner row of the visit in progress, 0xFFFFFFFF = none */
     float og[2];
-    float goff[2];     /* chain_mode 6: accumulator advance this chain started with */
-    float *o;          /* private copy of the owner row (ka floats) */
-    int shared;        /* chain_mode 2: the visit works on the row in memory */
+    float *o;     /* private copy of the owner row (ka floats) */
 } pl_list;
+
+typedef struct {
+    int visit;      /* index of the visit in progress inside the task, -1 before the first */
+    uint32_t until; /* first step after it */
+    float *copy;    /* ka floats + 2 accumulator slots: the "LDS" copy; then the same again: the state it started from */
+    float tsum0, tsum;
+} pl_wg;
 
 static float damp(float S) { return S > 1e-3f ? (1.0f - expf(-S)) / S : 1.0f - 0.5f * S; }
 
-int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long long *slot_task_ptr, int ns, int G,
+int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long long *slot_task_ptr, const void *wg_tasks_v,
+                         const void *wg_visits_v, const long long *slot_wg_ptr, const unsigned *hot_rows, int ns, int G, int W,
                          int ka, int owner_is_q, float *P, float *Q, float *PG, float *QG, long long n_hot_slots,
-                         float lambda_p, float lambda_q, float eta, int epochs, int first_epoch, int chain_mode,
+                         float lambda_p, float lambda_q, float eta, int epochs, int first_epoch, int mode,
                          int rsqrt_mode, int rk_mode, double *epoch_loss)
 {
     const pl_entry *entries = (const pl_entry *)entries_v;
     const pl_task *tasks = (const pl_task *)tasks_v;
+    const pl_wgtask *wgt = (const pl_wgtask *)wg_tasks_v;
+    const pl_wgvisit *wgv = (const pl_wgvisit *)wg_visits_v;
     float *own_rows = owner_is_q ? Q : P, *gat_rows = owner_is_q ? P : Q;
     float *own_acc = owner_is_q ? QG : PG, *gat_acc = owner_is_q ? PG : QG;
     const float lam_own = owner_is_q ? lambda_q : lambda_p, lam_gat = owner_is_q ? lambda_p : lambda_q;
     const float rk1 = (rk_mode == ORC_RK_AS_BUILT || ka == 8) ? 0.125f : 1.0f / (float)(ka - 8);
-    float *hot_growth = (float *)calloc((size_t)(n_hot_slots > 0 ? n_hot_slots : 1) * 2, sizeof(float));
-    float *hot_acc = (float *)calloc((size_t)(n_hot_slots > 0 ? n_hot_slots : 1) * (size_t)(ka + 4), sizeof(float));
-    int *hot_done = (int *)calloc((size_t)(n_hot_slots > 0 ? n_hot_slots : 1), sizeof(int));
-    long long max_tasks = 0;
+    const size_t nslots = (size_t)(n_hot_slots > 0 ? n_hot_slots : 1);
+    float *hot_acc = (float *)calloc(nslots * (size_t)(ka + 5), sizeof(float)); /* row, 2 acc, errors, ratings, copies */
+    long long max_tasks = 0, max_wg = 0;
     int i, ep;
-    const double study_pow = getenv("ORC_STUDY_POW") ? atof(getenv("ORC_STUDY_POW")) : 0.0;
-    const double study_reg = getenv("ORC_STUDY_REG") ? atof(getenv("ORC_STUDY_REG")) : 0.0;
-    const int study_dump = getenv("ORC_STUDY_DUMP") ? atoi(getenv("ORC_STUDY_DUMP")) : 0;
-    const int study_dump_minn = getenv("ORC_STUDY_DUMP_MINN") ? atoi(getenv("ORC_STUDY_DUMP_MINN")) : 0;
-    int dumped = 0;
-    const double study_blend = getenv("ORC_STUDY_BLEND") ? atof(getenv("ORC_STUDY_BLEND")) : 0.0;
-    const double study_smul = getenv("ORC_STUDY_SMUL") ? atof(getenv("ORC_STUDY_SMUL")) : 0.7; /* = HOT_S_GAIN of kernels.hpp */
-    const double study_rgain = getenv("ORC_STUDY_RGAIN") ? atof(getenv("ORC_STUDY_RGAIN")) : 1.0;
-    const int study_nform = getenv("ORC_STUDY_NFORM") ? atoi(getenv("ORC_STUDY_NFORM")) : 2; /* as the kernel: gain * (n / n0 + 1)^npow */
-    const double study_n0 = getenv("ORC_STUDY_N0") ? atof(getenv("ORC_STUDY_N0")) : 2.0; /* = HOT_S_N0 of kernels.hpp */
-    const double study_npow = getenv("ORC_STUDY_NPOW") ? atof(getenv("ORC_STUDY_NPOW")) : 0.5; /* = HOT_S_POW of kernels.hpp */
-    const int study_avg = getenv("ORC_STUDY_AVG") != NULL;
-    const double study_gain = getenv("ORC_STUDY_GAIN") ? atof(getenv("ORC_STUDY_GAIN")) : 1.0;
     pl_list *lists;
-    float *copies;
-    for (i = 0; i < ns * ns; i++)
-        if (slot_task_ptr[i + 1] - slot_task_ptr[i] > max_tasks)
-            max_tasks = slot_task_ptr[i + 1] - slot_task_ptr[i];
-    lists = (pl_list *)malloc((size_t)max_tasks * G * sizeof(pl_list));
-    copies = (float *)malloc((size_t)max_tasks * G * ka * sizeof(float));
+    pl_wg *wgs;
+    float *copies, *wcopies, *snap = (float *)malloc(sizeof(float) * (size_t)(ka + 2)), *tmp = (float *)malloc(sizeof(float) * (size_t)(ka + 2));
+    float *gsnap = (float *)malloc(sizeof(float) * (size_t)(ka + 2) * (size_t)G);
+    for (i = 0; i < ns * ns; i++) {
+        if (slot_task_ptr[i + 1] - slot_task_ptr[i] > max_tasks) max_tasks = slot_task_ptr[i + 1] - slot_task_ptr[i];
+        if (slot_wg_ptr[i + 1] - slot_wg_ptr[i] > max_wg) max_wg = slot_wg_ptr[i + 1] - slot_wg_ptr[i];
+    }
+    lists = (pl_list *)malloc((size_t)(max_tasks > 0 ? max_tasks : 1) * G * sizeof(pl_list));
+    copies = (float *)malloc((size_t)(max_tasks > 0 ? max_tasks : 1) * G * ka * sizeof(float));
+    wgs = (pl_wg *)malloc((size_t)(max_wg > 0 ? max_wg : 1) * sizeof(pl_wg));
+    wcopies = (float *)malloc((size_t)(max_wg > 0 ? max_wg : 1) * 2 * (size_t)(ka + 2) * sizeof(float));
 
     for (ep = first_epoch; ep < first_epoch + epochs; ep++) {
         const int slow = ep == 0;
@@ -92,214 +90,220 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
             const int r = (ri + ep) % ns; /* the kernel rotates the first round per epoch (trainer.cpp) */
             int s;
             for (s = 0; s < ns; s++) {
-                const long long tbeg = slot_task_ptr[(long long)r * ns + s], tend = slot_task_ptr[(long long)r * ns + s + 1];
+                const long long bi = (long long)r * ns + s;
+                const long long tbeg = slot_task_ptr[bi], tend = slot_task_ptr[bi + 1];
+                const long long wbeg = slot_wg_ptr[bi], wend = slot_wg_ptr[bi + 1];
                 const long long nl = (tend - tbeg) * G;
-                long long l, step, maxsteps = 0;
+                long long l, step, maxsteps = 0, t;
                 for (l = 0; l < nl; l++) {
                     lists[l].cur = 0xFFFFFFFFu;
-                    lists[l].hot_n = 0;
-                    lists[l].tsum = 0;
                     lists[l].o = copies + l * ka;
-                    lists[l].shared = 0;
                 }
-                for (l = tbeg; l < tend; l++)
-                    if (tasks[l].nsteps > maxsteps)
-                        maxsteps = tasks[l].nsteps;
-                for (step = 0; step <= maxsteps; step++) {
-                    long long t;
-                    for (t = tbeg; t < tend; t++) {
+                for (t = wbeg; t < wend; t++) {
+                    wgs[t - wbeg].visit = -1;
+                    wgs[t - wbeg].until = 0;
+                    wgs[t - wbeg].copy = wcopies + (t - wbeg) * 2 * (ka + 2);
+                    wgs[t - wbeg].tsum = 0;
+                    if (wgt[t].nsteps > maxsteps) maxsteps = wgt[t].nsteps;
+                }
+                for (t = tbeg; t < tend; t++)
+                    if (tasks[t].nsteps > maxsteps) maxsteps = tasks[t].nsteps;
+                for (step = 0; step <= maxsteps * (getenv("ORC_SEQ_PHASES") ? 2 : 1) + 1; step++) {
+                    const int seq = getenv("ORC_SEQ_PHASES") != NULL;
+                    const long long wstep = step, tstep = seq ? step - maxsteps - 1 : step;
+                    /* ---- workgroup tasks: the heavy rows ---- */
+                    for (t = wbeg; t < wend && wstep <= maxsteps; t++) {
+                        pl_wg *Wg = &wgs[t - wbeg];
+                        const pl_wgtask *T = &wgt[t];
+                        const int sw = (int)T->swapped;
+                        float *o_rows = sw ? gat_rows : own_rows, *o_acc = sw ? gat_acc : own_acc;
+                        float *g_rows = sw ? own_rows : gat_rows, *g_acc = sw ? own_acc : gat_acc;
+                        const float lo = sw ? lam_gat : lam_own, lg = sw ? lam_own : lam_gat;
+                        int w, g, d;
+                        if (step > T->nsteps) continue;
+                        if ((uint32_t)step == Wg->until) { /* a visit ends here (and the next one starts) */
+                            if (Wg->visit >= 0 && mode != 2) {
+                                const pl_wgvisit *V = &wgv[T->visit0 + Wg->visit];
+                                const unsigned ncop = V->info >> 1;
+                                float *rowp = o_rows + (size_t)V->row * ka, *accp = o_acc + (size_t)V->row * 2;
+                                const float *c = Wg->copy, *c0 = Wg->copy + ka + 2;
+                                if (ncop <= 1) { /* the one copy of the row is written back (like the owner row of a wave task) */
+                                    memcpy(rowp, c, sizeof(float) * ka);
+                                    accp[0] = c[ka];
+                                    accp[1] = c[ka + 1];
+                                } else {
+                                    float *slot = hot_acc + (size_t)V->slot * (ka + 5);
+                                    for (d = 0; d < ka; d++) slot[d] += c[d] - c0[d];
+                                    slot[ka] += c[ka] - c0[ka];
+                                    slot[ka + 1] += c[ka + 1] - c0[ka + 1];
+                                    slot[ka + 2] += Wg->tsum - Wg->tsum0;
+                                    slot[ka + 3] += (float)V->len;
+                                    slot[ka + 4] += 1.0f;
+                                }
+                            }
+                            if ((uint32_t)step >= T->nsteps) {
+                                Wg->until = 0xFFFFFFFFu;
+                                continue;
+                            }
+                            Wg->visit++;
+                            {
+                                const pl_wgvisit *V = &wgv[T->visit0 + Wg->visit];
+                                Wg->until = (uint32_t)step + V->nsteps;
+                                memcpy(Wg->copy, o_rows + (size_t)V->row * ka, sizeof(float) * ka);
+                                Wg->copy[ka] = o_acc[(size_t)V->row * 2];
+                                Wg->copy[ka + 1] = o_acc[(size_t)V->row * 2 + 1];
+                                memcpy(Wg->copy + ka + 2, Wg->copy, sizeof(float) * (ka + 2));
+                                Wg->tsum0 = Wg->tsum;
+                            }
+                        }
+                        if ((uint32_t)step >= T->nsteps) continue;
+                        {
+                            const pl_wgvisit *V = &wgv[T->visit0 + Wg->visit];
+                            for (w = 0; w < W; w++) {
+                                const pl_entry *eb = entries + T->off + (uint64_t)w * T->nsteps * G + (uint64_t)step * G;
+                                /* the wave reads the copy once per step; its G lists add what they change.  The rows of the
+                                   other side are read by all G lists before any of them writes (one step of a wave = one
+                                   burst of loads, then one burst of stores): of two lists that hold the same row in the
+                                   same step, the later one's store wins */
+                                if (mode != 2) memcpy(snap, Wg->copy, sizeof(float) * (ka + 2));
+                                if (mode != 2 && mode != 4)
+                                    for (g = 0; g < G; g++)
+                                        if (eb[g].gat >= 0) {
+                                            memcpy(gsnap + (size_t)g * (ka + 2), g_rows + (size_t)eb[g].gat * ka, sizeof(float) * ka);
+                                            memcpy(gsnap + (size_t)g * (ka + 2) + ka, g_acc + (size_t)eb[g].gat * 2, sizeof(float) * 2);
+                                        }
+                                for (g = 0; g < G; g++) {
+                                    const pl_entry e = eb[g];
+                                    float err;
+                                    if (e.gat < 0) continue;
+                                    if (mode == 4) memcpy(snap, Wg->copy, sizeof(float) * (ka + 2));
+                                    if (mode == 2) {
+                                        err = orc_sgd_one(o_rows + (size_t)V->row * ka, g_rows + (size_t)e.gat * ka, o_acc + (size_t)V->row * 2,
+                                                          g_acc + (size_t)e.gat * 2, e.r, ka, lo, lg, eta, slow, rsqrt_mode, rk_mode);
+                                    } else {
+                                        float *gr = mode == 4 ? g_rows + (size_t)e.gat * ka : gsnap + (size_t)g * (ka + 2);
+                                        float *ga = mode == 4 ? g_acc + (size_t)e.gat * 2 : gr + ka;
+                                        memcpy(tmp, snap, sizeof(float) * (ka + 2));
+                                        err = orc_sgd_one(tmp, gr, tmp + ka, ga, e.r, ka, lo, lg, eta, slow, rsqrt_mode, rk_mode);
+                                        for (d = 0; d < ka + 2; d++) Wg->copy[d] += tmp[d] - snap[d];
+                                    }
+                                    Wg->tsum += err * err;
+                                    loss += (double)(err * err);
+                                }
+                                if (mode != 2 && mode != 4)
+                                    for (g = 0; g < G; g++)
+                                        if (eb[g].gat >= 0) {
+                                            memcpy(g_rows + (size_t)eb[g].gat * ka, gsnap + (size_t)g * (ka + 2), sizeof(float) * ka);
+                                            memcpy(g_acc + (size_t)eb[g].gat * 2, gsnap + (size_t)g * (ka + 2) + ka, sizeof(float) * 2);
+                                        }
+                            }
+                        }
+                    }
+                    /* ---- wave tasks: the ordinary rows ---- */
+                    for (t = tbeg; t < tend && tstep >= 0; t++) {
                         int g;
+                        const long long step = tstep;
                         const int ended = step >= tasks[t].nsteps;
-                        if (step > tasks[t].nsteps)
-                            continue;
+                        int acts[64];
+                        pl_entry es[64];
+                        if (step > tasks[t].nsteps) continue;
+                        /* one step of a wave: visits are switched, then all G lists read their row of the other side, then all
+                           write it (of two lists that hold the same row in the same step, the later one's store wins) */
                         for (g = 0; g < G; g++) {
                             pl_list *L = &lists[(t - tbeg) * G + g];
                             pl_entry e;
-                            int act, hdr, newvisit;
+                            int act, newvisit;
                             uint32_t id;
                             if (ended) { /* the list is through: close the visit it holds */
-                                e.own = 0x80000000u | 0x7FFFFFFFu;
-                                e.gat = -1;
-                                e.r = 0;
-                                act = hdr = 0;
+                                act = 0;
                                 id = 0x7FFFFFFFu;
                                 newvisit = L->cur != 0xFFFFFFFFu;
+                                e.own = 0;
+                                e.gat = -1;
+                                e.r = 0;
                             } else {
                                 e = entries[tasks[t].off + (uint64_t)step * G + g];
                                 act = e.gat >= 0;
-                                hdr = e.gat < -1;
-                                id = e.own & 0x7FFFFFFFu;
-                                newvisit = (act || hdr) && (e.own >> 31) && (id != L->cur || hdr);
+                                id = e.own & IDMASK;
+                                newvisit = act && (e.own >> 31) && id != L->cur;
                             }
+                            acts[g] = act;
+                            es[g] = e;
                             if (newvisit) {
-                                if (L->cur != 0xFFFFFFFFu && !L->shared) { /* close_visit */
-                                    float *rowp = own_rows + (size_t)L->cur * ka, *accp = own_acc + (size_t)L->cur * 2;
-                                    int d;
-                                    if (L->hot_n != 0 && chain_mode == 6) {
-                                        float *slot = hot_acc + (size_t)(L->hot_h & 0xFFFFFu) * (ka + 4);
-                                        const int nch = L->hot_n & 0x7FFF;
-                                        for (d = 0; d < ka; d++)
-                                            slot[d] += L->o[d] - rowp[d];
-                                        slot[ka] += L->og[0] - accp[0] - L->goff[0];
-                                        slot[ka + 1] += L->og[1] - accp[1] - L->goff[1];
-                                        slot[ka + 2] += L->tsum - L->e0;
-                                        slot[ka + 3] += (float)(L->hot_h >> 20);
-                                        if (++hot_done[L->hot_h & 0xFFFFFu] == nch) {
-                                            const float A0 = slot[ka], A1 = slot[ka + 1], E = slot[ka + 2], N = slot[ka + 3];
-                                            const float ts0 = 1.0f / (sqrtf(accp[0] + A0) + sqrtf(accp[0])), ts1 = 1.0f / (sqrtf(accp[1] + A1) + sqrtf(accp[1]));
-                                            const float cq = E > 0.0f ? 2.0f * eta * N / E : 0.0f;
-                                            const float Sseq = ts0 * cq * A0 * 8.0f + ts1 * cq * A1 / rk1;
-                                            const float phi = damp((float)study_smul * Sseq) / damp((float)study_smul * Sseq / (float)nch);
-                                            float *gr = hot_growth + (size_t)(L->hot_h & 0xFFFFFu) * 2;
-                                            for (d = 0; d < ka; d++)
-                                                rowp[d] += phi * slot[d];
-                                            accp[0] += A0;
-                                            accp[1] += A1;
-                                            gr[0] = A0 / (float)nch;
-                                            gr[1] = A1 / (float)nch;
-                                            memset(slot, 0, sizeof(float) * (ka + 4));
-                                            hot_done[L->hot_h & 0xFFFFFu] = 0;
-                                        }
-                                    } else if (L->hot_n != 0 && (chain_mode == 4 || chain_mode == 5)) {
-                                        /* 4: rows are folded as a plain damped sum (phi of mode 1 without the step-size ratio);
-                                           5: only the accumulator growth is summed */
-                                        float *slot = hot_acc + (size_t)(L->hot_h & 0xFFFFFu) * (ka + 4);
-                                        const int nch = L->hot_n & 0x7FFF;
-                                        if (chain_mode == 4)
-                                            for (d = 0; d < ka; d++)
-                                                slot[d] += L->o[d] - rowp[d];
-                                        else {
-                                            slot[ka] += L->og[0] - accp[0];
-                                            slot[ka + 1] += L->og[1] - accp[1];
-                                        }
-                                        if (++hot_done[L->hot_h & 0xFFFFFu] == nch) {
-                                            if (chain_mode == 4)
-                                                for (d = 0; d < ka; d++)
-                                                    rowp[d] += slot[d] / (float)nch * (float)study_gain;
-                                            else {
-                                                accp[0] += slot[ka];
-                                                accp[1] += slot[ka + 1];
-                                            }
-                                            memset(slot, 0, sizeof(float) * (ka + 4));
-                                            hot_done[L->hot_h & 0xFFFFFu] = 0;
-                                        }
-                                    } else if (L->hot_n != 0 && chain_mode == 3) {
-                                        const int nch = L->hot_n & 0x7FFF, idx = L->hot_n >> 16;
-                                        float *slot = hot_acc + (size_t)(L->hot_h & 0xFFFFFu) * (ka + 4);
-                                        const float g0[2] = {accp[0], accp[1]};
-                                        const float Ac[2] = {L->og[0] - g0[0], L->og[1] - g0[1]};
-                                        const float Ec = L->tsum - L->e0, Nc = (float)(L->hot_h >> 20);
-                                        const float rk[2] = {0.125f, rk1};
-                                        float w[2], R = 0.0f;
-                                        int j;
-                                        for (j = 0; j < 2; j++) {
-                                            /* step size of this place in the visit over the step size the chain used */
-                                            w[j] = (sqrtf(g0[j] + Ac[j]) + sqrtf(g0[j])) /
-                                                   (sqrtf(g0[j] + (idx + 1) * Ac[j]) + sqrtf(g0[j] + idx * Ac[j]));
-                                            /* contraction of the chains behind this one: curvature x integrated step size */
-                                            if (Ec > 0.0f && Ac[j] > 0.0f)
-                                                R += (Ac[j] / (rk[j] * Ec)) * eta * (Nc / Ac[j]) * 2.0f *
-                                                     (sqrtf(g0[j] + nch * Ac[j]) - sqrtf(g0[j] + (idx + 1) * Ac[j]));
-                                        }
-                                        for (d = 0; d < ka; d++)
-                                            slot[d] += w[d >= 8] * expf(-(float)study_rgain * R) * (L->o[d] - rowp[d]);
-                                        slot[ka] += Ac[0];
-                                        slot[ka + 1] += Ac[1];
-                                        if (++hot_done[L->hot_h & 0xFFFFFu] == nch) {
-                                            for (d = 0; d < ka; d++)
-                                                rowp[d] += slot[d];
-                                            accp[0] += slot[ka];
-                                            accp[1] += slot[ka + 1];
-                                            memset(slot, 0, sizeof(float) * (ka + 4));
-                                            hot_done[L->hot_h & 0xFFFFFu] = 0;
-                                        }
-                                    } else if (L->hot_n == 0 || chain_mode == 0) {
-                                        memcpy(rowp, L->o, sizeof(float) * ka);
-                                        accp[0] = L->og[0];
-                                        accp[1] = L->og[1];
-                                    } else {
-                                        float *slot = hot_acc + (size_t)(L->hot_h & 0xFFFFFu) * (ka + 4);
-                                        for (d = 0; d < ka; d++)
-                                            slot[d] += L->o[d] - rowp[d];
-                                        slot[ka] += L->og[0] - accp[0];
-                                        slot[ka + 1] += L->og[1] - accp[1];
-                                        slot[ka + 2] += L->tsum - L->e0;
-                                        slot[ka + 3] += (float)(L->hot_h >> 20);
-                                        if (++hot_done[L->hot_h & 0xFFFFFu] == (L->hot_n & 0x7FFF)) { /* fold */
-                                            const float A0 = slot[ka], A1 = slot[ka + 1], E = slot[ka + 2], N = slot[ka + 3];
-                                            const float rn = 1.0f / (float)(L->hot_n & 0x7FFF);
-                                            const float r00 = sqrtf(accp[0]), r01 = sqrtf(accp[1]);
-                                            const float ts0 = 1.0f / (sqrtf(accp[0] + A0) + r00), ts1 = 1.0f / (sqrtf(accp[1] + A1) + r01);
-                                            const float tc0 = 1.0f / (sqrtf(accp[0] + A0 * rn) + r00), tc1 = 1.0f / (sqrtf(accp[1] + A1 * rn) + r01);
-                                            const float cq = E > 0.0f ? 2.0f * eta * N / E : 0.0f;
-                                            const float c0 = cq * A0 * 8.0f, c1 = cq * A1 / rk1;
-                                            const float reg = (float)study_reg * 2.0f * eta * N * lam_own / (float)ka; /* curvature of the L2 term */
-                                            const float Sseq = ts0 * (c0 + 8 * reg) + ts1 * (c1 + (ka - 8) * reg),
-                                                        Sch = (tc0 * (c0 + 8 * reg) + tc1 * (c1 + (ka - 8) * reg)) * rn;
-                                            const float nn = (float)(L->hot_n & 0x7FFF);
-                                            const float geff = (float)study_smul * (study_nform == 1 ? fmaxf(1.0f, nn / (float)study_n0)
-                                                                                    : study_nform == 2 ? powf(nn / (float)study_n0 + 1.0f, (float)study_npow) : 1.0f);
-                                            const float phi = damp(geff * Sseq) / damp(geff * Sch);
-                                            if (study_dump && ep == study_dump && (L->hot_n & 0x7FFF) >= study_dump_minn && dumped < 4000 && (dumped++ % 4) == 0)
-                                                fprintf(stderr, "fold ep %d n %d N %.0f G0 %.1f %.1f A %.2f %.2f E %.1f Sseq %.3f Sch %.3f phi %.3f sc %.3f %.3f\n", ep,
-                                                        L->hot_n & 0x7FFF, N, accp[0], accp[1], A0, A1, E, Sseq, Sch, phi, ts0 / tc0, ts1 / tc1);
-                                            for (d = 0; d < ka; d++)
-                                                rowp[d] += (study_blend > 0 ? (float)study_blend * rn + (1.0f - (float)study_blend) * phi * (d >= 8 ? ts1 / tc1 : ts0 / tc0) : study_avg ? rn * (float)study_gain : study_pow > 0 ? powf(d >= 8 ? ts1 / tc1 : ts0 / tc0, (float)study_pow) : phi * (d >= 8 ? ts1 / tc1 : ts0 / tc0)) * slot[d];
-                                            accp[0] += A0;
-                                            accp[1] += A1;
-                                            memset(slot, 0, sizeof(float) * (ka + 4));
-                                            hot_done[L->hot_h & 0xFFFFFu] = 0;
-                                        }
-                                    }
+                                if (L->cur != 0xFFFFFFFFu) { /* close_visit: the row is written back */
+                                    memcpy(own_rows + (size_t)L->cur * ka, L->o, sizeof(float) * ka);
+                                    own_acc[(size_t)L->cur * 2] = L->og[0];
+                                    own_acc[(size_t)L->cur * 2 + 1] = L->og[1];
                                 }
                                 if (ended) {
                                     L->cur = 0xFFFFFFFFu;
                                     continue;
                                 }
-                                L->hot_n = hdr ? ((-e.gat - 1) & 0x7FFF) | ((-e.gat - 1) >> 15 << 16) : 0; /* chains | index << 16 */
-                                memcpy(&L->hot_h, &e.r, 4);
-                                L->e0 = L->tsum;
-                                L->shared = hdr && chain_mode == 2;
                                 L->cur = id;
-                                if (!L->shared) {
-                                    memcpy(L->o, own_rows + (size_t)id * ka, sizeof(float) * ka);
-                                    L->og[0] = own_acc[(size_t)id * 2];
-                                    L->og[1] = own_acc[(size_t)id * 2 + 1];
-                                    L->goff[0] = L->goff[1] = 0.0f;
-                                    if (hdr && chain_mode == 6) {
-                                        const int idx = L->hot_n >> 16;
-                                        const float *gr = hot_growth + (size_t)(L->hot_h & 0xFFFFFu) * 2;
-                                        L->goff[0] = idx * gr[0];
-                                        L->goff[1] = idx * gr[1];
-                                        L->og[0] += L->goff[0];
-                                        L->og[1] += L->goff[1];
-                                    }
-                                }
-                            }
-                            if (act) {
-                                /* study modes: 4 = private row copy but the accumulators live in memory; 5 = the reverse */
-                                const int hotc = L->hot_n != 0;
-                                float *orow = (L->shared || (hotc && chain_mode == 5)) ? own_rows + (size_t)id * ka : L->o;
-                                float *oacc = (L->shared || (hotc && chain_mode == 4)) ? own_acc + (size_t)id * 2 : L->og;
-                                float *grow = gat_rows + (size_t)e.gat * ka, *gacc = gat_acc + (size_t)e.gat * 2;
-                                float err;
-                                /* orc_sgd_one(p, q, ...): p takes lambda_p; pass the owner as "p" with its own lambda */
-                                err = orc_sgd_one(orow, grow, oacc, gacc, e.r, ka, lam_own, lam_gat, eta, slow, rsqrt_mode, rk_mode);
-                                L->tsum += err * err;
-                                loss += (double)(err * err);
+                                memcpy(L->o, own_rows + (size_t)id * ka, sizeof(float) * ka);
+                                L->og[0] = own_acc[(size_t)id * 2];
+                                L->og[1] = own_acc[(size_t)id * 2 + 1];
                             }
                         }
+                        if (ended) continue;
+                        for (g = 0; g < G; g++)
+                            if (acts[g]) {
+                                memcpy(gsnap + (size_t)g * (ka + 2), gat_rows + (size_t)es[g].gat * ka, sizeof(float) * ka);
+                                memcpy(gsnap + (size_t)g * (ka + 2) + ka, gat_acc + (size_t)es[g].gat * 2, sizeof(float) * 2);
+                            }
+                        for (g = 0; g < G; g++)
+                            if (acts[g]) {
+                                pl_list *L = &lists[(t - tbeg) * G + g];
+                                float *gr = mode == 2 || mode == 4 ? gat_rows + (size_t)es[g].gat * ka : gsnap + (size_t)g * (ka + 2);
+                                float *ga = mode == 2 || mode == 4 ? gat_acc + (size_t)es[g].gat * 2 : gr + ka;
+                                const float err = orc_sgd_one(L->o, gr, L->og, ga, es[g].r, ka, lam_own, lam_gat, eta, slow, rsqrt_mode, rk_mode);
+                                loss += (double)(err * err);
+                            }
+                        if (mode != 2 && mode != 4)
+                            for (g = 0; g < G; g++)
+                                if (acts[g]) {
+                                    memcpy(gat_rows + (size_t)es[g].gat * ka, gsnap + (size_t)g * (ka + 2), sizeof(float) * ka);
+                                    memcpy(gat_acc + (size_t)es[g].gat * 2, gsnap + (size_t)g * (ka + 2) + ka, sizeof(float) * 2);
+                                }
                     }
                 }
             }
+            /* ---- behind the round: fold the rows that were split over several workgroups (fold_hot_rows) ---- */
+            for (i = 0; i < (int)n_hot_slots && mode != 2; i++) {
+                float *slot = hot_acc + (size_t)i * (ka + 5);
+                const float n = slot[ka + 4];
+                int d;
+                if (!(n > 0.0f)) continue;
+                {
+                    const unsigned hr = hot_rows[i];
+                    float *rowp = ((hr >> 31) ? gat_rows : own_rows) + (size_t)(hr & 0x7FFFFFFFu) * ka;
+                    float *accp = ((hr >> 31) ? gat_acc : own_acc) + (size_t)(hr & 0x7FFFFFFFu) * 2;
+                    const float A0 = fmaxf(slot[ka], 0.0f), A1 = fmaxf(slot[ka + 1], 0.0f), E = slot[ka + 2], N = slot[ka + 3];
+                    const float rn = 1.0f / n;
+                    const float r00 = sqrtf(accp[0]), r01 = sqrtf(accp[1]);
+                    const float ts0 = 1.0f / (sqrtf(accp[0] + A0) + r00), ts1 = 1.0f / (sqrtf(accp[1] + A1) + r01);
+                    const float tc0 = 1.0f / (sqrtf(accp[0] + A0 * rn) + r00), tc1 = 1.0f / (sqrtf(accp[1] + A1 * rn) + r01);
+                    const float cq = E > 0.0f ? 2.0f * eta * N / E : 0.0f;
+                    const float c0 = cq * A0 * 8.0f, c1 = cq * A1 / rk1;
+                    const float Sseq = ts0 * c0 + ts1 * c1, Sch = (tc0 * c0 + tc1 * c1) * rn;
+                    const float phi = damp(Sseq) / damp(Sch);
+                    const float sc0 = mode == 3 ? rn : phi * ts0 / tc0, sc1 = mode == 3 ? rn : phi * ts1 / tc1;
+                    for (d = 0; d < (slow ? 8 : ka); d++) rowp[d] += (d >= 8 ? sc1 : sc0) * slot[d];
+                    accp[0] += A0;
+                    accp[1] += A1;
+                    memset(slot, 0, sizeof(float) * (size_t)(ka + 5));
+                }
+            }
         }
-        if (epoch_loss)
-            epoch_loss[ep - first_epoch] = loss;
+        if (epoch_loss) epoch_loss[ep - first_epoch] = loss;
     }
     free(lists);
     free(copies);
-    free(hot_growth);
+    free(wgs);
+    free(wcopies);
+    free(snap);
+    free(tmp);
+    free(gsnap);
     free(hot_acc);
-    free(hot_done);
     return 0;
 }

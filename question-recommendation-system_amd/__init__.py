@@ -19,6 +19,10 @@ WARP_PATH = os.path.join(_HERE, "lib", "libmfwarp.so")
 NODE = np.dtype([("u", "<i4"), ("v", "<i4"), ("r", "<f4")])  # mf_node, reference mf/mf.h:36-41
 ENTRY = np.dtype([("own", "<u4"), ("gat", "<i4"), ("r", "<f4")])
 TASK = np.dtype([("off", "<u8"), ("nsteps", "<u4"), ("pad", "<u4")])
+# workgroup tasks (the heavy rows, include/mfx.h mfx_plan_view): entries stored wave-major, visits tile the steps
+WGTASK = np.dtype([("off", "<u8"), ("nsteps", "<u4"), ("visit0", "<u4"), ("nvisits", "<u4"), ("swapped", "<u4")])
+WGVISIT = np.dtype([("row", "<u4"), ("nsteps", "<u4"), ("len", "<u4"), ("info", "<u4"), ("slot", "<u4"), ("pad", "<u4")])
+ENTRY_SWAPPED, ENTRY_ID_MASK = 0x40000000, 0x3FFFFFFF
 
 # Itanium names of the five symbols an unchanged libphp_mf.so imports
 MANGLED = {
@@ -37,7 +41,7 @@ class MfxError(RuntimeError):
 class Options(C.Structure):
     _fields_ = [("k", C.c_int), ("lambda_p2", C.c_float), ("lambda_q2", C.c_float),
                 ("eta", C.c_float), ("device", C.c_int), ("stripes", C.c_int),
-                ("wg_per_cu", C.c_int), ("task_steps", C.c_int), ("reserved0", C.c_int),
+                ("wg_per_cu", C.c_int), ("task_steps", C.c_int), ("swap_heavy", C.c_int),
                 ("rk_mode", C.c_int), ("owner_side", C.c_int), ("identity_maps", C.c_int),
                 ("use_stats", C.c_int), ("stats_avg", C.c_float), ("stats_std", C.c_float),
                 ("reserved", C.c_int * 1)]
@@ -52,7 +56,9 @@ class Info(C.Structure):
                 ("owner_is_q", C.c_int), ("n_entries", C.c_longlong), ("n_tasks", C.c_longlong),
                 ("n_hot_rows", C.c_longlong), ("cu_count", C.c_int), ("xcd_count", C.c_int),
                 ("wg_per_cu", C.c_int), ("dP", C.c_void_p), ("dQ", C.c_void_p),
-                ("dPG", C.c_void_p), ("dQG", C.c_void_p), ("bytes_per_rating", C.c_double)]
+                ("dPG", C.c_void_p), ("dQG", C.c_void_p), ("bytes_per_rating", C.c_double),
+                ("n_wg_tasks", C.c_longlong), ("n_wg_visits", C.c_longlong), ("n_hot_slots", C.c_longlong),
+                ("hot_acc_bytes", C.c_longlong), ("waves_per_wg", C.c_int), ("hot_len", C.c_int)]
 
 
 class PlanView(C.Structure):
@@ -65,7 +71,10 @@ class PlanView(C.Structure):
                 ("inv_scale", C.c_float), ("p_map", C.c_void_p), ("q_map", C.c_void_p),
                 ("omega_p", C.c_void_p), ("omega_q", C.c_void_p), ("entries", C.c_void_p),
                 ("tasks", C.c_void_p), ("slot_task_ptr", C.c_void_p),
-                ("p_begin", C.c_void_p), ("q_begin", C.c_void_p), ("n_hot_slots", C.c_longlong)]
+                ("p_begin", C.c_void_p), ("q_begin", C.c_void_p), ("n_hot_slots", C.c_longlong),
+                ("wg_tasks", C.c_void_p), ("wg_visits", C.c_void_p), ("slot_wg_ptr", C.c_void_p),
+                ("n_wg_tasks", C.c_longlong), ("n_wg_visits", C.c_longlong), ("waves_per_wg", C.c_int),
+                ("hot_len", C.c_int), ("hot_rows", C.c_void_p)]
 
 
 _lib = None
@@ -104,6 +113,9 @@ def lib():
     L.mfx_trainer_maps.argtypes = [vp, vp, vp]
     L.mfx_trainer_get_model.argtypes = [vp, vp, vp, vp, vp]
     L.mfx_trainer_plan_copy.argtypes = [vp, vp, vp, vp]
+    L.mfx_trainer_plan_copy_wg.argtypes = [vp, vp, vp, vp]
+    L.mfx_predict_cache_enable.argtypes = [i32]
+    L.mfx_predict_cache_enable.restype = None
     L.mfx_trainer_set_model.argtypes = [vp, vp, vp, vp, vp]
     L.mfx_trainer_layout_fingerprint.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.mfx_trainer_epochs_done.argtypes = [vp]
@@ -243,6 +255,11 @@ def predict_cache_drop():
     lib().mfx_predict_cache_drop()
 
 
+def predict_cache_enable(on=True):
+    """Opt in to keeping the model array of utility_predict resident in HBM between calls (mfx_predict_cache_enable)."""
+    lib().mfx_predict_cache_enable(1 if on else 0)
+
+
 def rmse_array(model, R):
     mdl = np.ascontiguousarray(model, dtype=np.float32)
     R = np.ascontiguousarray(R, dtype=NODE)
@@ -378,6 +395,15 @@ class Trainer:
         _check(lib().mfx_trainer_plan_copy(self._h, e.ctypes.data, t.ctypes.data, sp.ctypes.data))
         return e, t, sp
 
+    def plan_copy_wg(self):
+        """(wg_tasks, wg_visits, slot_wg_ptr): the workgroup tasks of the layout resident in HBM."""
+        i = self.info
+        w = np.empty(i.n_wg_tasks, dtype=WGTASK)
+        v = np.empty(i.n_wg_visits, dtype=WGVISIT)
+        sp = np.empty(i.stripes * i.stripes + 1, dtype=np.int64)
+        _check(lib().mfx_trainer_plan_copy_wg(self._h, w.ctypes.data, v.ctypes.data, sp.ctypes.data))
+        return w, v, sp
+
     def get_model(self):
         i = self.info
         P = np.empty((i.m, i.k_aligned), dtype=np.float32)
@@ -460,6 +486,10 @@ class HostPlan:
         self.slot_task_ptr = arr(v.slot_task_ptr, v.stripes * v.stripes + 1, np.int64)
         self.p_begin = arr(v.p_begin, v.stripes + 1, np.int32)
         self.q_begin = arr(v.q_begin, v.stripes + 1, np.int32)
+        self.wg_tasks = arr(v.wg_tasks, v.n_wg_tasks, WGTASK)
+        self.wg_visits = arr(v.wg_visits, v.n_wg_visits, WGVISIT)
+        self.slot_wg_ptr = arr(v.slot_wg_ptr, v.stripes * v.stripes + 1, np.int64)
+        self.hot_rows = arr(v.hot_rows, v.n_hot_slots, np.uint32)
 
     def init_factors(self):
         v = self.view

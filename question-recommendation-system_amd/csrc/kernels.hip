@@ -63,6 +63,12 @@ __device__ __forceinline__ float group_sum(float x)
     return x;
 }
 
+// LDS float add without a return value (ds_add_f32)
+__device__ __forceinline__ void lds_add(float *p, float v)
+{
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __device__ __forceinline__ int xcc_id()
 {
     int x;
@@ -141,6 +147,10 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
     __shared__ u4 ering_all[4][2 * EBLK]; // per wave: a ring of two blocks, 16-byte slots
     u4 *const ering = ering_all[threadIdx.x >> 6];
     __shared__ int wg_first;
+    // workgroup tasks: the heavy row of the visit in progress lives here (LDS float atomics from every list of the workgroup)
+    __shared__ f4 lrow4[64];
+    __shared__ float lacc[2];
+    __shared__ float lE;
 #ifdef MFX_OWNER_LDS
     // experiment (make variant VFLAGS=-DMFX_OWNER_LDS): the "LDS-staged latent tile" for the one side that has re-use -- the
     // owner row of a visit lives in LDS (read before and written after every update) instead of in registers
@@ -200,6 +210,209 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                 return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(d.off >> 32)) << 32) |
                        (unsigned)__builtin_amdgcn_readfirstlane((int)(d.off & 0xFFFFFFFFu));
             };
+            // ---- workgroup tasks: the heavy rows of the block (plan.hpp "workgroup tasks") ----
+            // Claimed by whole workgroups before any wave task.  The W waves x G lane groups of the workgroup advance through
+            // the ratings of ONE heavy row side by side; the row and its two accumulator slots live in LDS for the length
+            // of the visit and every list updates them with LDS float atomics -- one copy, no lost update: the sequential
+            // meaning of the order up to the W x G ratings in flight.  The other side of these ratings is read-modified-
+            // written through the XCD's L2 exactly as in a wave task.  With the roles swapped (heavy row of the GATHERED side)
+            // the same code runs on the other side's pointers, descriptors and lambda.
+            {
+                const long long wbeg = a.slot_wg_ptr[slot];
+                const int nwg = (int)(a.slot_wg_ptr[slot + 1] - wbeg);
+                const int wv = (int)(threadIdx.x >> 6);
+                while (nwg > 0) {
+                    __syncthreads(); // (wg_first is reused)
+                    if (threadIdx.x == 0) wg_first = atomicAdd(&a.wg_cursor[slot], 1);
+                    __syncthreads();
+                    const int wt = __builtin_amdgcn_readfirstlane(wg_first);
+                    if (wt >= nwg) break;
+                    const WgTaskD *const tp = a.wg_tasks + wbeg + wt;
+                    const unsigned long long toff = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(tp->off >> 32)) << 32) |
+                                                    (unsigned)__builtin_amdgcn_readfirstlane((int)(tp->off & 0xFFFFFFFFu));
+                    const int tsteps = __builtin_amdgcn_readfirstlane((int)tp->nsteps);
+                    const int visit0 = __builtin_amdgcn_readfirstlane((int)tp->visit0);
+                    const int nvisits = __builtin_amdgcn_readfirstlane((int)tp->nvisits);
+                    const bool sw = __builtin_amdgcn_readfirstlane((int)tp->swapped) != 0;
+                    float *const o_rows = sw ? a.gat_rows : a.own_rows, *const o_acc = sw ? a.gat_acc : a.own_acc;
+                    // the side that is read-modified-written: the gathered stripe, or (roles swapped) the owner stripe
+                    const __amdgpu_buffer_rsrc_t w_rows = sw ? make_rsrc(a.own_rows + (size_t)ofirst * ka, (unsigned)on_rows * (unsigned)(ka * 4)) : rs_rows;
+                    const __amdgpu_buffer_rsrc_t w_acc = sw ? make_rsrc(a.own_acc + (size_t)ofirst * 2, (unsigned)on_rows * 8u) : rs_acc;
+                    const int wfirst = sw ? ofirst : gfirst;
+                    const float wl_o = sw ? lam_g : lam_o, wl_g = sw ? lam_o : lam_g;
+                    const EntryD *const ebase = a.entries + toff + (size_t)wv * (size_t)tsteps * G;
+                    const int nent = tsteps * G;
+                    auto fetch_block = [&](int blk, EntryD &r0, EntryD &r1) {
+                        const int i0 = blk * EBLK + lane, i1 = i0 + 64;
+                        r0 = ebase[i0 < nent ? i0 : nent - 1];
+                        r1 = ebase[i1 < nent ? i1 : nent - 1];
+                    };
+                    auto park_block = [&](int blk, const EntryD &r0, const EntryD &r1) {
+                        const int i0 = (blk * EBLK + lane) & (2 * EBLK - 1);
+                        ering[i0] = u4{r0.own, (unsigned)r0.gat, __builtin_bit_cast(unsigned, r0.r), 0u};
+                        ering[i0 + 64] = u4{r1.own, (unsigned)r1.gat, __builtin_bit_cast(unsigned, r1.r), 0u};
+                    };
+                    auto entry_of = [&](int step) {
+                        const u4 v = ering[(step * G + grp) & (2 * EBLK - 1)];
+                        const unsigned rbits = v.z;
+                        return EntryD{v.x, (int)v.y, __builtin_bit_cast(float, rbits)};
+                    };
+                    EntryD r0 = {0u, -1, 0.0f}, r1 = {0u, -1, 0.0f}, e = {0u, -1, 0.0f};
+                    unsigned grow = BUF_OOB, gacc = BUF_OOB;
+                    f4 gn = zero4;
+                    f2 ggn = {1.0f, 1.0f};
+                    if (wave_on) {
+                        fetch_block(0, r0, r1);
+                        park_block(0, r0, r1);
+                        e = entry_of(0);
+                        grow = e.gat >= 0 && lane_ok ? (unsigned)(e.gat - wfirst) * (unsigned)(ka * 4) + d0 * 4 : BUF_OOB;
+                        gacc = e.gat >= 0 ? (unsigned)(e.gat - wfirst) * 8u : BUF_OOB;
+                        gn = bld_row(w_rows, grow);
+                        ggn = bld_acc(w_acc, gacc);
+                    }
+                    float tsum = 0.0f;
+                    int step = 0;
+                    for (int v = 0; v < nvisits; ++v) {
+                        const WgVisitD *const vp = a.wg_visits + visit0 + v;
+                        const unsigned row = (unsigned)__builtin_amdgcn_readfirstlane((int)vp->row);
+                        const int vsteps = __builtin_amdgcn_readfirstlane((int)vp->nsteps);
+                        const unsigned vlen = (unsigned)__builtin_amdgcn_readfirstlane((int)vp->len);
+                        const unsigned vinfo = (unsigned)__builtin_amdgcn_readfirstlane((int)vp->info);
+                        const unsigned vslot = (unsigned)__builtin_amdgcn_readfirstlane((int)vp->slot);
+                        __syncthreads(); // the visit before is through with the LDS row (its write-back included)
+                        f4 x0 = zero4;
+                        f2 g0 = {1.0f, 1.0f};
+                        if (wv == 0 && grp == 0) {
+                            if (lane_ok) {
+                                x0 = ld_row(o_rows + (size_t)row * ka + d0);
+                                lrow4[lig] = x0;
+                            }
+                            if (lig == 0) {
+                                g0 = ld_acc(o_acc + (size_t)row * 2);
+                                lacc[0] = g0.x;
+                                lacc[1] = g0.y;
+                                lE = 0.0f;
+                            }
+                        }
+                        __syncthreads();
+                        const float tsum0 = tsum;
+                        auto wg_step = [&]() {
+                                const EntryD enext = entry_of(step + 1);
+                                const bool act = e.gat >= 0;
+                                const float rating = e.r;
+                                f4 g = gn;
+                                f2 gg = ggn;
+                                const unsigned grow_c = grow, gacc_c = gacc;
+                                asm volatile("" : "+v"(g.x), "+v"(g.y), "+v"(g.z), "+v"(g.w), "+v"(gg.x), "+v"(gg.y));
+                                const int sib = step & (EBLK / G - 1);
+                                const int blk1 = step / (EBLK / G) + 1;
+                                if (sib == 0 && blk1 * EBLK < nent) fetch_block(blk1, r0, r1);
+                                if (sib == EBLK / G - 2 && blk1 * EBLK < nent) park_block(blk1, r0, r1);
+                                // the heavy row as it is NOW (other lists keep adding to it)
+                                const f4 o = lane_ok ? lrow4[lig] : zero4;
+                                const float og0 = lacc[0], og1 = lacc[1];
+                                f2 o01 = {o.x, o.y}, o23 = {o.z, o.w}, g01 = {g.x, g.y}, g23 = {g.z, g.w};
+                                const f2 zz = o01 * g01 + o23 * g23;
+                                const float z = group_sum<LANES>(zz.x + zz.y);
+                                const float err = act ? rating - z : 0.0f;
+                                tsum += err * err;
+                                const float eta_o = eta * __builtin_amdgcn_rsqf(slot1 ? og1 : og0);
+                                const float eta_g = eta * __builtin_amdgcn_rsqf(slot1 ? gg.y : gg.x);
+                                float so = 0.0f, sg = 0.0f;
+                                f2 d01 = {0.0f, 0.0f}, d23 = {0.0f, 0.0f};
+                                const bool move = upd && act;
+                                if (move) {
+                                    const f2 go01 = wl_o * o01 - err * g01, go23 = wl_o * o23 - err * g23;
+                                    const f2 gq01 = wl_g * g01 - err * o01, gq23 = wl_g * g23 - err * o23;
+                                    const f2 so2 = go01 * go01 + go23 * go23, sg2 = gq01 * gq01 + gq23 * gq23;
+                                    so = so2.x + so2.y;
+                                    sg = sg2.x + sg2.y;
+                                    d01 = -eta_o * go01;
+                                    d23 = -eta_o * go23;
+                                    g01 -= eta_g * gq01;
+                                    g23 -= eta_g * gq23;
+                                    g = f4{g01.x, g01.y, g23.x, g23.y};
+                                }
+                                const bool nact = enext.gat >= 0 && step + 1 < tsteps;
+                                grow = nact && lane_ok ? (unsigned)(enext.gat - wfirst) * (unsigned)(ka * 4) + d0 * 4 : BUF_OOB;
+                                gacc = nact ? (unsigned)(enext.gat - wfirst) * 8u : BUF_OOB;
+                                bst_row(w_rows, grow_c, g);
+                                {
+                                    const float sg0 = group_sum<LANES>(slot1 ? 0.0f : sg);
+                                    gg.x = gg.x + sg0 * rk0;
+                                    if (!SLOW) {
+                                        const float sg1 = group_sum<LANES>(slot1 ? sg : 0.0f);
+                                        gg.y = gg.y + sg1 * rk1;
+                                    }
+                                    bst_acc(w_acc, gacc_c, gg);
+                                }
+                                gn = bld_row(w_rows, grow);
+                                ggn = bld_acc(w_acc, gacc);
+                                // the heavy row's own update: LDS float atomics (ds_add_f32), so that no list's change is lost
+                                if (move) {
+                                    float *const lr = (float *)lrow4 + d0;
+                                    lds_add(lr + 0, d01.x);
+                                    lds_add(lr + 1, d01.y);
+                                    lds_add(lr + 2, d23.x);
+                                    lds_add(lr + 3, d23.y);
+                                }
+                                const float so0 = group_sum<LANES>(slot1 ? 0.0f : so);
+                                if (lig == 0 && act) lds_add(&lacc[0], so0 * rk0);
+                                if (!SLOW) {
+                                    const float so1 = group_sum<LANES>(slot1 ? so : 0.0f);
+                                    if (lig == 0 && act) lds_add(&lacc[1], so1 * rk1);
+                                }
+                                e = enext;
+                        };
+                        // The FIRST step of a visit is taken by the waves in turn.  Side by side, W x G lists would all read
+                        // the row as the visit found it and add their steps to it at once; while the row's accumulators are
+                        // still small (epoch 0: G = 1, step size eta itself) that sum overshoots -- 128 simultaneous
+                        // ratings at k = 8 move the row 4 x beyond its optimum and the visit never recovers.  After one
+                        // step in turn the accumulators hold W x G ratings' growth and the steps are small enough to add.
+                        for (int s = 0; s < vsteps; ++s, ++step) {
+                            if (s == 0) {
+                                for (int tw = 0; tw < a.active_waves; ++tw) {
+                                    if (wv == tw) wg_step();
+                                    __syncthreads();
+                                }
+                            } else if (wave_on) {
+                                wg_step();
+                            }
+                        }
+                        if (wave_on && lig == 0) lds_add(&lE, tsum - tsum0);
+                        __syncthreads(); // every list's adds have landed
+                        if (wv == 0 && grp == 0) {
+                            // One workgroup held ALL of the row's ratings of this block: the copy is the row, written back like the
+                            // owner row of a wave task.  A row split over several workgroups: every copy adds what it CHANGED
+                            // (end state minus the state it started from -- sums of end states cancel catastrophically for a
+                            // row of many copies), its squared errors, its ratings and 1 to the row's combine slot with
+                            // fire-and-forget float atomics; fold_hot_rows, launched behind the round, folds the copies.
+                            const unsigned ncop = vinfo >> 1;
+                            if (ncop <= 1) {
+                                if (lane_ok) *(f4 *)(o_rows + (size_t)row * ka + d0) = lrow4[lig];
+                                if (lig == 0) *(f2 *)(o_acc + (size_t)row * 2) = f2{lacc[0], lacc[1]};
+                            } else {
+                                float *const dst = a.hot_acc + ((size_t)vslot * HOT_SUB + (size_t)(wt & (HOT_SUB - 1))) * (size_t)(ka + HOT_EXTRA);
+                                if (lane_ok) {
+                                    const f4 x1 = lrow4[lig];
+                                    unsafeAtomicAdd(dst + d0 + 0, x1.x - x0.x);
+                                    unsafeAtomicAdd(dst + d0 + 1, x1.y - x0.y);
+                                    unsafeAtomicAdd(dst + d0 + 2, x1.z - x0.z);
+                                    unsafeAtomicAdd(dst + d0 + 3, x1.w - x0.w);
+                                }
+                                if (lig == 0) {
+                                    unsafeAtomicAdd(dst + ka, lacc[0] - g0.x);
+                                    unsafeAtomicAdd(dst + ka + 1, lacc[1] - g0.y);
+                                    unsafeAtomicAdd(dst + ka + 2, lE);           // squared errors of this copy
+                                    unsafeAtomicAdd(dst + ka + 3, (float)vlen);  // its ratings
+                                    unsafeAtomicAdd(dst + ka + 4, 1.0f);         // one more copy
+                                }
+                            }
+                        }
+                    }
+                    if (wave_on && lig == 0) lsum += (double)tsum;
+                }
+            }
             STAMP(tk0);
             // The first claim of a launch is made once per workgroup, not once per wave: every wave
             // of the XCD asks at the same moment, and atomics on one address take ~70 cycles each.
@@ -254,12 +467,8 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                 int nsteps_n = 0;
 
                 unsigned cur = NONE;  // owner row held in registers
-                int hot_n = 0;        // > 0: the visit in progress is one of hot_n chains of a hot row (this launch)
-                unsigned hot_h = 0;   //      with combine slot (bits 0..19) and this chain's length (bits 20..31)
-                float hot_e0 = 0.0f;  //      list's squared-error sum when the chain began
-                f4 o = zero4, o_start = zero4;
+                f4 o = zero4;
                 float og0 = 1.0f, og1 = 1.0f;
-                f2 og_start = {1.0f, 1.0f};
                 unsigned pf = NONE;   // owner row in flight for the next visit
                 f4 on = zero4;
                 f2 ogn = {1.0f, 1.0f};
@@ -297,7 +506,7 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                 EntryD r0 = nb0, r1 = nb1; // block 0 was fetched while the task before ran
                 park_block(0, r0, r1);
                 EntryD e = entry_of(0);
-                if (e.gat != -1) { // every list starts with a visit (or the header of a hot chain): fetch its owner row now
+                if (e.gat != -1) { // every list starts with a visit: fetch its owner row now
                     pf = e.own & IDMASK;
                     if (lane_ok) on = ld_row(a.own_rows + (size_t)pf * ka + d0);
                     ogn = ld_acc(a.own_acc + (size_t)pf * 2);
@@ -321,41 +530,12 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                 c_task += tk1 - tk0;
                 n_tasks++;
 #endif
-                // ---- hot chains ----
-                // An owner row with more ratings in the block than one list should hold is cut into chains
-                // (plan.cpp), each run on its own register copy of the row -- possibly at the same time in
-                // other waves.  A chain does not write the row: it adds what it CHANGED (row, the two accumulator
-                // slots; end state minus the start state it keeps in registers -- sums of end states cancel
-                // catastrophically for a row of 30 000 chains), its squared errors, its length and 1 to the row's
-                // combine slot with fire-and-forget float atomics; fold_hot_rows, launched behind every round,
-                // folds the sums into the row (see there).
-                // (A slot is HOT_SUB partial sums: hundreds of chains of one row adding to the same words would
-                //  queue at one memory channel, ~12 ns per wave instruction -- 47 us for the head row of configs[1].)
                 auto close_visit = [&]() {
 #ifdef MFX_OWNER_LDS
                     o = own_tile[threadIdx.x];
 #endif
-                    if (hot_n == 0) {
-                        if (lane_ok) *(f4 *)(a.own_rows + (size_t)cur * ka + d0) = o;
-                        if (lig == 0) *(f2 *)(a.own_acc + (size_t)cur * 2) = f2{og0, og1};
-                        return;
-                    }
-                    float *const slot = a.hot_acc + ((size_t)(hot_h & 0xFFFFFu) * HOT_SUB +
-                                                     (size_t)(((blockIdx.x * 4 + (threadIdx.x >> 6)) * G + grp) & (HOT_SUB - 1))) *
-                                                        (size_t)(ka + HOT_EXTRA);
-                    if (lane_ok) {
-                        unsafeAtomicAdd(slot + d0 + 0, o.x - o_start.x);
-                        unsafeAtomicAdd(slot + d0 + 1, o.y - o_start.y);
-                        unsafeAtomicAdd(slot + d0 + 2, o.z - o_start.z);
-                        unsafeAtomicAdd(slot + d0 + 3, o.w - o_start.w);
-                    }
-                    if (lig == 0) {
-                        unsafeAtomicAdd(slot + ka, og0 - og_start.x);
-                        unsafeAtomicAdd(slot + ka + 1, og1 - og_start.y);
-                        unsafeAtomicAdd(slot + ka + 2, tsum - hot_e0);        // squared errors of this chain
-                        unsafeAtomicAdd(slot + ka + 3, (float)(hot_h >> 20)); // its ratings
-                        unsafeAtomicAdd(slot + ka + 4, 1.0f);                 // one more chain
-                    }
+                    if (lane_ok) *(f4 *)(a.own_rows + (size_t)cur * ka + d0) = o;
+                    if (lig == 0) *(f2 *)(a.own_acc + (size_t)cur * 2) = f2{og0, og1};
                 };
                 for (int step = 0; step < nsteps; ++step) {
                     STAMP(ts0);
@@ -365,13 +545,9 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     const bool act = e.gat >= 0;
                     const unsigned id = e.own & IDMASK;
                     const float rating = e.r;
-                    const bool hdr = e.gat < -1; // header entry of a hot chain: always starts a visit of its own
-                    const bool newvisit = (act || hdr) && (e.own >> 31) && (id != cur || hdr);
+                    const bool newvisit = act && (e.own >> 31) && id != cur;
                     if (newvisit) { // switch the owner row: write the old one back, take the prefetched one
                         if (cur != NONE) close_visit();
-                        hot_n = hdr ? ((-e.gat - 1) & 0x7FFF) | ((-e.gat - 1) >> 15 << 16) : 0; // chains | index << 16
-                        hot_h = __builtin_bit_cast(unsigned, rating);
-                        hot_e0 = tsum;
                         if (pf != id) { // not prefetched (cannot happen for lists built by plan.cpp)
                             if (lane_ok) on = ld_row(a.own_rows + (size_t)id * ka + d0);
                             ogn = ld_acc(a.own_acc + (size_t)id * 2);
@@ -382,8 +558,6 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
 #endif
                         og0 = ogn.x;
                         og1 = ogn.y;
-                        o_start = on; // (what a hot chain's change is measured against)
-                        og_start = ogn;
                         cur = id;
                     }
                     f4 g = gn;
@@ -451,8 +625,7 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     gacc = nact ? (unsigned)(enext.gat - gfirst) * 8u : BUF_OOB;
                     const unsigned id1 = enext.own & IDMASK;
                     auto owner_prefetch = [&]() {
-                        const bool nhdr = enext.gat < -1 && step + 1 < nsteps;
-                        if ((nact || nhdr) && (enext.own >> 31) && (id1 != cur || nhdr)) { // a visit starts at the next step
+                        if (nact && (enext.own >> 31) && id1 != cur) { // a visit starts at the next step
                             pf = id1;
                             if (lane_ok) on = ld_row(a.own_rows + (size_t)id1 * ka + d0);
                             ogn = ld_acc(a.own_acc + (size_t)id1 * 2);
@@ -550,55 +723,53 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
     }
 }
 
-// Fold the chains of the hot rows into their rows (launched behind every round; one wave per combine slot).
-// Round 1 let the last writer win: a row cut into n chains kept 1/n of its updates and of its accumulator growth,
-// so its step size stayed too large and the whole run fitted the training set 2-3 % faster than the reference.
-// Now no update and no accumulator increment is lost.  The fold is a 1-D model of what the reference does
-// sequentially (DESIGN.md "Hot rows"): all chains start from the row p0 of before the launch.  With
-// S = sum over the ratings of (step size x curvature), a sequential pass moves the row by (1 - exp(-S_seq)) of the
-// way to the block's optimum, a chain by (1 - exp(-S_chain)); the summed change of the n chains is therefore scaled
-// by (1 - exp(-S_seq)) / (n (1 - exp(-S_chain))): exactly 1 for one chain, the plain sum (first-order equivalence)
-// while S is small, never beyond the optimum for a row that holds a large part of the block.  Step sizes come from
-// the Adagrad accumulators (sequentially G runs from G0 to G0 + A, in a chain to G0 + A/n: mean step
-// 2 eta / (sqrt(G_end) + sqrt(G0))), the curvature |q|^2 from the accumulator growth over the squared errors
-// (A = rk * sum e^2 |q|^2): nothing extra is computed per rating.
-__global__ __launch_bounds__(256) void fold_hot_rows(float *rows, float *acc, float *hot_acc, const int *hot_row,
-                                                     int n_slots, int ka, float eta, float rk1, int slow_only, int fold_mode, float s_gain, float n0, float npow)
+// Fold the copies of the rows that are split over several workgroups into their rows (launched behind every round that
+// holds such a row; one wave per combine slot).  A row with more ratings in a block than one workgroup does in a launch
+// is worked on by n workgroups, each on its own LDS copy that starts from the row p0 of before the launch; every copy adds
+// what it changed -- row, both accumulator slots, squared errors, ratings -- to the row's combine slot.  Here the
+// accumulators grow by ALL copies' growth and the row moves by the copies' summed change times a damping factor, a 1-D
+// model of what one sequential pass over all n parts does (DESIGN.md "Heavy rows"): with S = sum over the ratings of
+// (step size x curvature), a sequential pass moves the row (1 - exp(-S_seq)) of the way to the block's optimum, one copy
+// (1 - exp(-S_copy)); the sum of the n copies is therefore scaled by (1 - exp(-S_seq)) / (n (1 - exp(-S_copy))): exactly 1
+// for one copy, the plain sum (first-order equivalence) while S is small, the mean of the copies when every copy
+// converges by itself.  Step sizes come from the Adagrad accumulators (sequentially G runs from G0 to G0 + A, in a copy
+// to G0 + A/n: mean step 2 eta / (sqrt(G_end) + sqrt(G0))), the curvature |q|^2 from the accumulator growth over the
+// squared errors (A = rk * sum e^2 |q|^2): nothing extra is computed per rating, and NO constant is fitted (rounds 1-2
+// cut such rows into hundreds of 128-rating chains and needed a calibrated gain on S; with a handful of long copies the
+// result no longer depends on the rule: the mean of the copies lands within 0.2 % of it, oracle/plan_order.c).
+// hot_row[slot] = internal row | side << 31 (1: a row of the plan's gathered side, whose visits ran with the roles swapped).
+__global__ __launch_bounds__(256) void fold_hot_rows(float *own_rows, float *own_acc, float *gat_rows, float *gat_acc, float *hot_acc,
+                                                     const int *hot_row, int n_slots, int ka, float eta, float rk1, int slow_only)
 {
     const int lane = threadIdx.x & 63;
     const int slot_i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot_i >= n_slots) return;
     const int stride = ka + HOT_EXTRA;
     float *const s0 = hot_acc + (size_t)slot_i * HOT_SUB * stride;
-    float ex[HOT_EXTRA] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f}; // growth of both accumulator slots, squared errors, ratings, chains
+    float ex[HOT_EXTRA] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f}; // growth of both accumulator slots, squared errors, ratings, copies
     if (lane < HOT_EXTRA)
         for (int sub = 0; sub < HOT_SUB; ++sub) ex[0] += s0[(size_t)sub * stride + ka + lane];
     const float v = ex[0];
 #pragma unroll
     for (int j = 0; j < HOT_EXTRA; ++j) ex[j] = __shfl(v, j);
     const float n = ex[4];
-    if (!(n > 0.0f)) return; // the row had no chain in this round
-    const int row = hot_row[slot_i];
+    if (!(n > 0.0f)) return; // the row was not split in this round
+    const unsigned hr = (unsigned)hot_row[slot_i];
+    const int row = (int)(hr & 0x7FFFFFFFu);
+    float *const rows = (hr >> 31) ? gat_rows : own_rows, *const acc = (hr >> 31) ? gat_acc : own_acc;
     const float g00 = acc[(size_t)row * 2], g01 = acc[(size_t)row * 2 + 1];
     const float A0 = fmaxf(ex[0], 0.0f), A1 = fmaxf(ex[1], 0.0f), E = ex[2], N = ex[3];
     const float rn = 1.0f / n;
     const float r00 = __builtin_sqrtf(g00), r01 = __builtin_sqrtf(g01);
-    // mean step sizes (/ 2 eta) of a sequential pass and of a chain, per accumulator slot
+    // mean step sizes (/ 2 eta) of a sequential pass and of a copy, per accumulator slot
     const float ts0 = 1.0f / (__builtin_sqrtf(g00 + A0) + r00), ts1 = 1.0f / (__builtin_sqrtf(g01 + A1) + r01);
     const float tc0 = 1.0f / (__builtin_sqrtf(g00 + A0 * rn) + r00), tc1 = 1.0f / (__builtin_sqrtf(g01 + A1 * rn) + r01);
     const float cq = E > 0.0f ? 2.0f * eta * N / E : 0.0f; // sum of |q|^2 over the ratings, per slot: N * A / (rk * E)
     const float c0 = cq * A0 * 8.0f, c1 = cq * A1 / rk1;
     const float Sseq = ts0 * c0 + ts1 * c1, Sch = (tc0 * c0 + tc1 * c1) * rn;
     auto damp = [](float S) { return S > 1e-3f ? (1.0f - __expf(-S)) / S : 1.0f - 0.5f * S; };
-    // The gain on S (HOT_S_GAIN, growing with the chain count n as g * sqrt(n / n0 + 1), HOT_S_N0): private row copies are
-    // not a sequential pass -- a batch-like fold is a lower-variance estimator than a pass that tracks the last ratings it
-    // saw, the more so the more ratings the row has -- and under-moving the row is what stands in for that.  Calibrated
-    // on the order emulation (oracle/plan_order.c, tests/tools/order_study.py) and on the GPU over configs[1] at 12 and 20
-    // epochs, configs[2] at 8, 12 and 20 and its 20 M sample (DESIGN.md 4 "Hot rows").
-    const float geff = n0 > 0.0f ? s_gain * __powf(n / n0 + 1.0f, npow) : s_gain;
-    const float phi = damp(geff * Sseq) / damp(geff * Sch); // (1-exp(-S)) / (n (1-exp(-S/n))) in the symmetric case
-    // fold_mode 0: the damped sum above; 1 (experiment): the row becomes the MEAN of the chains' end states
-    const float sc0 = fold_mode == 1 ? rn : phi * ts0 / tc0, sc1 = fold_mode == 1 ? rn : phi * ts1 / tc1;
+    const float phi = damp(Sseq) / damp(Sch); // (1-exp(-S)) / (n (1-exp(-S/n))) in the symmetric case
+    const float sc0 = phi * ts0 / tc0, sc1 = phi * ts1 / tc1;
     for (int d = lane; d < (slow_only ? 8 : ka); d += 64) { // (epoch 0 moves the first eight factors only)
         float sum = 0.0f;
         for (int sub = 0; sub < HOT_SUB; ++sub) sum += s0[(size_t)sub * stride + d];
@@ -690,8 +861,9 @@ __global__ __launch_bounds__(256) void sq_err_entries(const float *own_rows, con
             EntryD e = entries[i];
             act = e.gat >= 0;
             if (act && lane_ok) {
-                f4 o = *(const f4 *)(own_rows + (size_t)(e.own & 0x7FFFFFFFu) * ka + d0);
-                f4 g = *(const f4 *)(gat_rows + (size_t)e.gat * ka + d0);
+                const bool sw = (e.own & 0x40000000u) != 0; // a heavy row of the gathered side: `own` indexes that side
+                f4 o = *(const f4 *)((sw ? gat_rows : own_rows) + (size_t)(e.own & 0x3FFFFFFFu) * ka + d0);
+                f4 g = *(const f4 *)((sw ? own_rows : gat_rows) + (size_t)e.gat * ka + d0);
                 z = o.x * g.x + o.y * g.y + o.z * g.z + o.w * g.w;
             }
             r = e.r;
@@ -807,12 +979,15 @@ __global__ __launch_bounds__(256) void export_side(const float *rows, const int 
 // Start of an epoch: every task of the epoch before must have been handed out (cursor >= task count per
 // block) -- if not, a sticky flag is raised that no later reset clears -- then the loss sums and the
 // cursors are zeroed.  One launch in place of the memset that used to do only the second half.
-__global__ __launch_bounds__(256) void epoch_reset(double *loss, int *cursor, const long long *slot_task_ptr, int nb,
-                                                  int check, int *sticky)
+__global__ __launch_bounds__(256) void epoch_reset(double *loss, int *cursor, const long long *slot_task_ptr,
+                                                  const long long *slot_wg_ptr, int nb, int check, int *sticky)
 {
-    for (int i = threadIdx.x; i < nb; i += 256) {
-        if (check && cursor[i] < (int)(slot_task_ptr[i + 1] - slot_task_ptr[i])) atomicOr(sticky, 1);
+    for (int i = threadIdx.x; i < nb; i += 256) { // wave-task cursors [0, nb), workgroup-task cursors [nb, 2 nb)
+        if (check && (cursor[i] < (int)(slot_task_ptr[i + 1] - slot_task_ptr[i]) ||
+                      cursor[nb + i] < (int)(slot_wg_ptr[i + 1] - slot_wg_ptr[i])))
+            atomicOr(sticky, 1);
         cursor[i] = 0;
+        cursor[nb + i] = 0;
     }
     for (int i = threadIdx.x; i < LOSS_SLOTS; i += 256) loss[i] = 0.0;
 }
@@ -869,12 +1044,12 @@ hipError_t launch_sgd_round(int lanes, const RoundArgs &a, int grid, hipStream_t
     return hipGetLastError();
 }
 
-hipError_t launch_fold_hot(float *rows, float *acc, float *hot_acc, const int *hot_row, int n_slots, int ka, float eta,
-                           float rk1, int slow_only, int fold_mode, float s_gain, float n0, float npow, hipStream_t s)
+hipError_t launch_fold_hot(float *own_rows, float *own_acc, float *gat_rows, float *gat_acc, float *hot_acc, const int *hot_row,
+                           int n_slots, int ka, float eta, float rk1, int slow_only, hipStream_t s)
 {
     if (n_slots <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fold_hot_rows, dim3((n_slots + 3) / 4), dim3(256), 0, s, rows, acc, hot_acc, hot_row, n_slots, ka,
-                       eta, rk1, slow_only, fold_mode, s_gain, n0, npow);
+    hipLaunchKernelGGL(fold_hot_rows, dim3((n_slots + 3) / 4), dim3(256), 0, s, own_rows, own_acc, gat_rows, gat_acc, hot_acc,
+                       hot_row, n_slots, ka, eta, rk1, slow_only);
     return hipGetLastError();
 }
 
@@ -937,10 +1112,10 @@ hipError_t launch_export(const float *rows, const int *map, int nrows, int k, in
     return hipGetLastError();
 }
 
-hipError_t launch_epoch_reset(double *loss, int *cursor, const long long *slot_task_ptr, int nb, int check, int *sticky,
-                              hipStream_t s)
+hipError_t launch_epoch_reset(double *loss, int *cursor, const long long *slot_task_ptr, const long long *slot_wg_ptr, int nb,
+                              int check, int *sticky, hipStream_t s)
 {
-    hipLaunchKernelGGL(epoch_reset, dim3(1), dim3(256), 0, s, loss, cursor, slot_task_ptr, nb, check, sticky);
+    hipLaunchKernelGGL(epoch_reset, dim3(1), dim3(256), 0, s, loss, cursor, slot_task_ptr, slot_wg_ptr, nb, check, sticky);
     return hipGetLastError();
 }
 

@@ -8,12 +8,11 @@ namespace mfx {
 // device views of plan.hpp's Entry / TaskDesc (same layout)
 struct EntryD { uint32_t own; int32_t gat; float r; };
 struct TaskDescD { uint64_t off; uint32_t nsteps; uint32_t pad; };
+struct WgTaskD { uint64_t off; uint32_t nsteps; uint32_t visit0; uint32_t nvisits; uint32_t swapped; };  // plan.hpp WgTask
+struct WgVisitD { uint32_t row; uint32_t nsteps; uint32_t len; uint32_t info; uint32_t slot; uint32_t pad; }; // WgVisitRec
 
 constexpr int LOSS_SLOTS = 256; // the epoch loss is kept as this many partial sums
 constexpr int HOT_SUB = 8;      // a hot row's combine slot is kept as this many partial sums of (ka + HOT_EXTRA) floats:
-constexpr float HOT_S_GAIN = 0.7f; // fold_hot_rows: gain on the contraction estimate (calibrated, see there)
-constexpr float HOT_S_N0 = 2.0f;   // > 0: the gain grows with the chain count, g * (n / n0 + 1)^HOT_S_POW
-constexpr float HOT_S_POW = 0.5f;
 constexpr int HOT_EXTRA = 5;    // the row, then both accumulator slots, squared errors, ratings, chains
 
 // Arguments of one SGD round (= one launch = NS stripe-disjoint blocks).
@@ -27,6 +26,10 @@ struct RoundArgs {
     const TaskDescD *tasks;
     const long long *slot_task_ptr; // ns+1 task offsets of this round
     int *slot_cursor;               // ns ints, zero before the launch
+    const WgTaskD *wg_tasks;        // workgroup tasks (heavy rows), claimed by whole workgroups before the wave tasks
+    const WgVisitD *wg_visits;
+    const long long *slot_wg_ptr;   // ns+1 workgroup-task offsets of this round
+    int *wg_cursor;                 // ns ints, zero before the launch
     double *loss;                   // LOSS_SLOTS partial sums of e^2 (scaled units), accumulated
     float lambda_own, lambda_gat, eta, rk1;
     int ka, slow_only, ns;
@@ -46,8 +49,8 @@ struct RoundArgs {
 };
 
 hipError_t launch_sgd_round(int lanes, const RoundArgs &a, int grid, hipStream_t s);
-hipError_t launch_fold_hot(float *rows, float *acc, float *hot_acc, const int *hot_row, int n_slots, int ka, float eta,
-                           float rk1, int slow_only, int fold_mode, float s_gain, float n0, float npow, hipStream_t s);
+hipError_t launch_fold_hot(float *own_rows, float *own_acc, float *gat_rows, float *gat_acc, float *hot_acc, const int *hot_row,
+                           int n_slots, int ka, float eta, float rk1, int slow_only, hipStream_t s);
 hipError_t launch_visibility_probe(int *ticket, float *row, int *flag, int *ack, int rounds, int *out, int grid, hipStream_t s);
 hipError_t launch_probe_xcc(unsigned *mask, int grid, hipStream_t s);
 hipError_t launch_sq_err_entries(int lanes, const float *own_rows, const float *gat_rows,
@@ -61,8 +64,8 @@ hipError_t launch_sq_err_nodes(const float *model, int m, int n, int k, float b,
                                long long nnz, double *out, int grid, hipStream_t s);
 hipError_t launch_export(const float *rows, const int *map, int nrows, int k, int ka, float f,
                          int do_scale, float *out, int grid, hipStream_t s);
-hipError_t launch_epoch_reset(double *loss, int *cursor, const long long *slot_task_ptr, int nb, int check, int *sticky,
-                              hipStream_t s);
+hipError_t launch_epoch_reset(double *loss, int *cursor, const long long *slot_task_ptr, const long long *slot_wg_ptr, int nb,
+                              int check, int *sticky, hipStream_t s);
 hipError_t launch_fill(float *p, long long n, float v, int grid, hipStream_t s);
 hipError_t launch_triplets(const float *tri, long long count, void *out, int *mn_bad, int grid, hipStream_t s);
 hipError_t launch_synth(unsigned long long seed, unsigned long long shard, long long first,

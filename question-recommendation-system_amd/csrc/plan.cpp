@@ -10,10 +10,12 @@
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <mutex>
 #include <queue>
 #include <stdexcept>
 #include <thread>
 
+#include "knobs.hpp"
 #include "rng.hpp"
 
 namespace mfx {
@@ -88,20 +90,18 @@ static void collect_info(const Node *R, long long nnz, int threads, float &avg, 
 
 namespace {
 
-struct Rat { uint32_t own; uint32_t gat; float r; };
+struct Rat { uint32_t own; uint32_t gat; float r; }; // (primary, secondary) of the sort: owner/gathered id, swapped for heavy gathered rows
 
-// Pack one class of visits into tasks whose lane-group lists hold about `target` ratings:
-// longest-processing-time-first into G*ntasks lists, lists of similar load share a task.
+// Pack the visits of the wave tasks (ordinary rows: at most hot_len ratings in the block) into `ntasks` tasks of G lists of
+// equal load: longest-processing-time-first, then every list runs its visits in ascending row id.
 void pack_class(const std::vector<Visit> &visits, size_t vbeg, size_t vend, int G, int target,
                 BlockPack &out, long long force_ntasks = 0)
 {
     if (vbeg >= vend) return;
-    static const int list_order = getenv("MFX_LIST_ORDER") ? atoi(getenv("MFX_LIST_ORDER")) : 1;
-    // load of a visit in steps: its ratings, plus the header entry of a hot chain
-    auto steps_of = [](const Visit &v) { return v.len + (v.nch ? 1u : 0u); };
+    const int list_order = knob_int("MFX_LIST_ORDER", 1);
     long long L = 0;
-    for (size_t i = vbeg; i < vend; ++i) L += steps_of(visits[i]);
-    target = std::max<long long>(target, steps_of(visits[vbeg])); // visits are sorted, longest first
+    for (size_t i = vbeg; i < vend; ++i) L += visits[i].len;
+    target = std::max<long long>(target, visits[vbeg].len); // visits are sorted, longest first
     long long ntasks = (L + (long long)G * target - 1) / ((long long)G * target);
     if (force_ntasks > 0) ntasks = force_ntasks;
     if (ntasks < 1) ntasks = 1;
@@ -121,7 +121,7 @@ void pack_class(const std::vector<Visit> &visits, size_t vbeg, size_t vend, int 
         else next[tail[lst]] = (uint32_t)(vi - vbeg);
         tail[lst] = (uint32_t)(vi - vbeg);
         ++count[lst];
-        const uint64_t key = top + ((uint64_t)steps_of(visits[vi]) << 32);
+        const uint64_t key = top + ((uint64_t)visits[vi].len << 32);
         load[lst] = (uint32_t)(key >> 32);
         size_t i = 0;
         const size_t n = (size_t)NG;
@@ -156,27 +156,21 @@ void pack_class(const std::vector<Visit> &visits, size_t vbeg, size_t vend, int 
             // run in does not matter for the load.  As packed (round 1) every launch did all its heavy rows first and
             // all its light rows last -- a systematic order the reference does not have (it walks a block sorted by
             // row id, mf.cpp:843-852), worth -0.6 % (20 M sample) to -1.9 % (configs[2]) of final RMSE by itself in the
-            // order emulation.  MFX_LIST_ORDER: 0 as packed, 1 by owner row id (default: the reference's own
-            // order inside a block; +0.9 % epoch time on configs[2]), 2 scattered by a hash (same fit, +3.3 % time).
+            // order emulation.  Lists therefore run their visits by owner row id (the reference's own
+            // order inside a block; experiment knob MFX_LIST_ORDER: 0 as packed, 2 scattered by a hash).
             lv.clear();
             lv.reserve(count[lst]);
             for (uint32_t x = head[lst]; x != NIL; x = next[x]) lv.push_back((uint32_t)(x + vbeg));
             if (list_order == 1)
-                std::sort(lv.begin(), lv.end(), [&](uint32_t a, uint32_t b) {
-                    return visits[a].own != visits[b].own ? visits[a].own < visits[b].own : visits[a].idx < visits[b].idx;
-                });
+                std::sort(lv.begin(), lv.end(), [&](uint32_t a, uint32_t b) { return visits[a].own < visits[b].own; });
             else if (list_order == 2)
                 std::sort(lv.begin(), lv.end(), [&](uint32_t a, uint32_t b) {
-                    const uint32_t ha = (visits[a].own * 2654435761u) ^ (visits[a].idx * 40503u), hb = (visits[b].own * 2654435761u) ^ (visits[b].idx * 40503u);
+                    const uint32_t ha = visits[a].own * 2654435761u, hb = visits[b].own * 2654435761u;
                     return ha != hb ? ha < hb : a < b;
                 });
             for (uint32_t vi : lv) {
                 const Visit &v = visits[vi];
-                if (v.nch) { // hot chain: a header entry first
-                    out.headers.push_back({base + (uint64_t)step * G + g, v.own, v.nch, v.hot | (v.len << 20), v.idx});
-                    ++step;
-                }
-                out.places.push_back({v.start, base + (uint64_t)step * G + g, v.len, 0u});
+                out.places.push_back({v.start, base + (uint64_t)step * G + g, v.len, 1u | 0x40000000u});
                 step += v.len;
             }
             out.padding += nsteps - step;
@@ -185,96 +179,196 @@ void pack_class(const std::vector<Visit> &visits, size_t vbeg, size_t vend, int 
     }
 }
 
+// steps one wave does in a launch if the block is dealt out evenly: ordinary ratings one per list step, the ratings of a
+// heavy row W x G per step of its workgroup
+long long block_steps_per_wave(const std::vector<Visit> &raw, int G, int W, int waves, int hot_len, long long *hot_steps_out = nullptr)
+{
+    const long long WGL = (long long)W * G;
+    long long L_main = 0, hot_steps = 0;
+    for (const Visit &v : raw) {
+        if (!v.swapped && (long long)v.len <= hot_len) L_main += v.len;
+        else hot_steps += ((long long)v.len + WGL - 1) / WGL;
+    }
+    if (hot_steps_out) *hot_steps_out = hot_steps;
+    const long long lists = (long long)std::max(1, waves) * G;
+    return std::max<long long>(1, (L_main + hot_steps * WGL + lists - 1) / lists);
+}
+
+// number of workgroups a heavy visit is split over: one, unless it holds more than a workgroup does in the launch
+inline long long visit_copies(uint32_t len, long long WGL, long long T)
+{
+    const long long steps = ((long long)len + WGL - 1) / WGL;
+    return std::max<long long>(1, (steps + T - 1) / T);
+}
+
+struct Piece { uint32_t vi; uint32_t idx; uint32_t steps; uint32_t len; uint64_t start; };
+
 } // namespace
 
-// Cut one (owner-stripe, gather-stripe) block, given as its visits, into wavefront tasks.
-void pack_visits(std::vector<Visit> &raw, int G, int target, int hot_len, BlockPack &out, int one_task_waves,
-                 const std::vector<int> *hot_slot_of_row)
+// Cut one (owner-stripe, gather-stripe) block, given as its visits, into workgroup tasks (heavy rows) and wave tasks.
+static void pack_block(std::vector<Visit> &raw, int G, int W, int waves, int target, int hot_len, int tasks_per_wave,
+                       const std::vector<int> &slot_own, const std::vector<int> &slot_gat, BlockPack &out)
 {
     if (raw.empty()) return;
-    // A visit (all ratings of one owner row in this block) longer than hot_len is cut into
-    // chains that may run in different lane groups, each on its own register copy of the owner row;
-    // when the last chain of the launch ends, the chains' changes are folded into the row (kernels.hip,
-    // "hot chains"; DESIGN.md "Hot rows").  No list is longer than the longest visit, so hot_len also
-    // bounds the longest task of the launch.
-    std::vector<Visit> visits;
+    const long long WGL = (long long)W * G;
+    long long hot_steps = 0;
+    const long long T = block_steps_per_wave(raw, G, W, waves, hot_len, &hot_steps);
+    std::vector<Visit> visits; // the ordinary ones
     visits.reserve(raw.size());
-    long long L = 0;
-    for (const Visit &v : raw) {
-        L += v.len;
-        if ((long long)v.len > hot_len) {
-            long long nch = ((long long)v.len + hot_len - 1) / hot_len;
-            if (nch > 32767) nch = 32767; // the header entry counts chains in 15 bits: a monster row gets longer chains instead
-            long long per = ((long long)v.len + nch - 1) / nch;
-            long long made = 0;
-            for (long long s = 0; s < v.len; s += per) ++made;
-            const uint32_t slot = hot_slot_of_row ? (uint32_t)(*hot_slot_of_row)[v.own] : 0u;
-            if (made >= (1 << 15) || per >= (1 << 12))
-                throw std::invalid_argument("one row holds more than 134 M ratings of a block: more stripes (mfx_options.stripes)");
-            for (long long s = 0; s < v.len; s += per)
-                visits.push_back({v.own, (uint32_t)std::min<long long>(per, v.len - s), v.start + (uint64_t)s,
-                                  hot_slot_of_row ? (uint32_t)made : 0u, slot, (uint32_t)(s / per)});
-            out.hot++;
-        } else {
+    std::vector<Piece> pieces[2]; // by role
+    for (size_t i = 0; i < raw.size(); ++i) {
+        const Visit &v = raw[i];
+        if (!v.swapped && (long long)v.len <= hot_len) {
             visits.push_back(v);
+            continue;
+        }
+        out.hot++;
+        const long long steps = ((long long)v.len + WGL - 1) / WGL, nc = visit_copies(v.len, WGL, T);
+        const long long per = (steps + nc - 1) / nc; // steps per copy
+        uint32_t idx = 0;
+        for (long long s0 = 0; s0 < steps; s0 += per, ++idx) {
+            const long long s1 = std::min(steps, s0 + per);
+            const uint64_t first = (uint64_t)s0 * WGL;
+            const uint32_t len = (uint32_t)(std::min<uint64_t>(v.len, (uint64_t)s1 * WGL) - first);
+            pieces[v.swapped ? 1 : 0].push_back({(uint32_t)i, idx, (uint32_t)(s1 - s0), len, v.start + first});
         }
     }
-    // longest first, equal lengths in their given order: a counting sort (lengths are at most hot_len unless a monster
-    // row got longer chains), the comparison sort otherwise
+    // workgroup tasks, per role: as many as the heavy work fills at T steps each, the pieces dealt longest first
+    int wgs_used = 0;
+    const int wgs_total = std::max(1, waves / std::max(1, W));
+    for (int role = 0; role < 2; ++role) {
+        std::vector<Piece> &pc = pieces[role];
+        if (pc.empty()) continue;
+        long long steps = 0;
+        for (const Piece &q : pc) steps += q.steps;
+        long long nt = std::max<long long>(1, (steps + T / 2) / T);
+        nt = std::min<long long>(nt, (long long)pc.size());
+        // leave the ordinary rows at least half of the workgroups
+        nt = std::min<long long>(nt, std::max(1, wgs_total / 2 - wgs_used));
+        std::stable_sort(pc.begin(), pc.end(), [](const Piece &a, const Piece &b) { return a.steps > b.steps; });
+        std::vector<long long> load((size_t)nt, 0);
+        std::vector<std::vector<uint32_t>> of((size_t)nt);
+        for (uint32_t i = 0; i < pc.size(); ++i) {
+            size_t best = 0;
+            for (size_t t = 1; t < (size_t)nt; ++t)
+                if (load[t] < load[best]) best = t;
+            of[best].push_back(i);
+            load[best] += pc[i].steps;
+        }
+        for (size_t t = 0; t < (size_t)nt; ++t) {
+            std::vector<uint32_t> &lst = of[t];
+            // by row id, like the lists of the wave tasks (the reference walks a block sorted by row, mf.cpp:843-852)
+            std::sort(lst.begin(), lst.end(), [&](uint32_t a, uint32_t b) {
+                const Visit &va = raw[pc[a].vi], &vb = raw[pc[b].vi];
+                return va.own != vb.own ? va.own < vb.own : pc[a].idx < pc[b].idx;
+            });
+            WgTask wt;
+            wt.off = out.n_entries;
+            wt.nsteps = (uint32_t)load[t];
+            wt.visit0 = (uint32_t)out.wg_visits.size();
+            wt.nvisits = (uint32_t)lst.size();
+            wt.swapped = (uint32_t)role;
+            const uint64_t wave_stride = (uint64_t)wt.nsteps * G;
+            out.n_entries += wave_stride * W;
+            uint32_t step0 = 0;
+            long long rated = 0;
+            for (uint32_t pi : lst) {
+                const Piece &q = pc[pi];
+                const Visit &v = raw[q.vi];
+                const long long nc = visit_copies(v.len, WGL, T);
+                WgVisitRec rec;
+                rec.v.row = v.own;
+                rec.v.nsteps = q.steps;
+                rec.v.len = q.len;
+                rec.v.info = ((uint32_t)nc << 1) | (uint32_t)role;
+                rec.slot = 0;
+                rec.pad = 0;
+                if (nc > 1) {
+                    const int sl = (role ? slot_gat : slot_own)[v.own];
+                    if (sl < 0) throw std::logic_error("split row without a combine slot");
+                    rec.slot = (uint32_t)sl;
+                    out.folds = true;
+                }
+                out.wg_visits.push_back(rec);
+                // The piece's ratings (sorted by the other side's id) are dealt over the W x G lists in CONTIGUOUS runs of
+                // `steps` ratings, not round-robin: ratings of one pair -- the synthetic streams repeat pairs, a heavy user
+                // rates a heavy item thousands of times -- then sit one behind the other in ONE list, where the second
+                // sees what the first did; side by side in one step they would all read the other row before any of them
+                // wrote it.
+                for (long long l = 0; l < WGL; ++l) {
+                    const long long first = l * (long long)q.steps;
+                    if (first >= (long long)q.len) break;
+                    const uint32_t cnt = (uint32_t)std::min<long long>(q.steps, (long long)q.len - first);
+                    const long long w = l / G, g = l % G;
+                    out.places.push_back({q.start + (uint64_t)first, wt.off + (uint64_t)w * wave_stride + (uint64_t)step0 * G + (uint64_t)g, cnt,
+                                          1u | (role ? 0x80000000u : 0u)});
+                }
+                step0 += q.steps;
+                rated += q.len;
+            }
+            out.padding += (long long)(wave_stride * W) - rated;
+            out.wg_tasks.push_back(wt);
+        }
+        wgs_used += (int)nt;
+    }
+    if (visits.empty()) return;
+    // longest first, equal lengths in their given order: a counting sort (lengths are at most hot_len)
     uint32_t max_len = 0;
     for (const Visit &v : visits) max_len = std::max(max_len, v.len);
-    if (max_len <= 65536u) {
+    {
         std::vector<size_t> at((size_t)max_len + 2, 0);
         for (const Visit &v : visits) at[(size_t)(max_len - v.len) + 1]++;
         for (size_t i = 1; i < at.size(); ++i) at[i] += at[i - 1];
         std::vector<Visit> sorted(visits.size());
         for (const Visit &v : visits) sorted[at[(size_t)(max_len - v.len)]++] = v;
         visits.swap(sorted);
-    } else {
-        std::stable_sort(visits.begin(), visits.end(),
-                         [](const Visit &a, const Visit &b) { return a.len > b.len; });
     }
-
-    // Graded task sizes: the first half of the work goes into full-size tasks, then a
-    // quarter at half size, ... so the waves that drain the block's queue last are holding
-    // short tasks (the launch ends when the slowest wave does).
-    if (one_task_waves > 0) { // equal-load tasks, (tasks per wave) x (waves of the block's XCD) of them
-        pack_class(visits, 0, visits.size(), G, 8, out, one_task_waves);
+    const int waves_main = std::max(std::min(W, waves), waves - W * wgs_used);
+    if (tasks_per_wave > 0) { // equal-load tasks, (tasks per wave) x (waves left for the ordinary rows) of them
+        pack_class(visits, 0, visits.size(), G, 8, out, (long long)tasks_per_wave * waves_main);
         return;
     }
-    const double frac[4] = {0.5, 0.75, 0.875, 1.0};
-    const char *ge = getenv("MFX_GRADES"); // experiment knob: number of size classes (1..4)
-    const int grades = ge && *ge ? std::max(1, std::min(4, atoi(ge))) : 4;
-    size_t vbeg = 0;
-    long long acc = 0;
-    for (int c = 0; c < grades; ++c) {
-        size_t vend = vbeg;
-        if (c == grades - 1) {
-            vend = visits.size();
-        } else {
-            while (vend < visits.size() && acc < (long long)(frac[c] * (double)L)) acc += visits[vend++].len;
-        }
-        pack_class(visits, vbeg, vend, G, std::max(8, target >> c), out);
-        vbeg = vend;
-    }
+    pack_class(visits, 0, visits.size(), G, std::max(8, target), out); // explicit task_steps (tests): tasks of that size
 }
 
 void plan_sizes(long long nnz, int NB, int G, const PlanConfig &cfg, int &target, int &hot_len)
 {
-    // Full-size tasks hold about half of what one wave does in a launch (same T for every
-    // block: a block that is heavier than average must not get longer tasks, its XCD would
-    // finish the round last); the graded tail in pack_visits keeps the end short.
     const long long per_wave = nnz / ((long long)NB * G * std::max(1, cfg.waves_per_stripe));
     target = cfg.task_steps;
     if (target <= 0) target = (int)std::min<long long>(64, std::max<long long>(8, per_wave / 2));
-    // A hot owner row is cut into chains of at most hot_len ratings.  Longer chains keep more of
-    // the row's updates (measured: 128 vs 64 is worth 2-3 % RMSE on small problems,
-    // profiles/experiments/r01_hot_chain_length.log), but a list must not outlast what one wave
-    // does in the launch, or it sets the launch time: hot_len = per-wave load, within [48,128] (48: below it the
-    // ordinary rows of small blocks get cut too -- one rank of N=8: RMSE 0.730 at 38, 0.698 at 48).
-    const char *he = getenv("MFX_HOT_LEN"); // experiment knob
-    hot_len = he && *he ? std::max(8, atoi(he))
-                        : (int)std::min<long long>(128, std::max<long long>(48, per_wave));
+    // A row with more ratings in a block than hot_len goes to a workgroup task.  A list must not outlast what one wave
+    // does in the launch, or it sets the launch time: hot_len = per-wave load, within [48,128] (48: below it the ordinary
+    // rows of small blocks would all become heavy).
+    hot_len = knob_int("MFX_HOT_LEN", (int)std::min<long long>(128, std::max<long long>(48, per_wave)));
+    if (hot_len < 8) hot_len = 8;
+    // A launch of ONE workgroup per XCD (tiny problems) has nobody to run workgroup tasks beside the wave tasks: the
+    // workgroup would do all heavy rows of a block first and all ordinary rows after them, an order the reference does
+    // not have (+2 % final RMSE on 2000 x 1500 problems).  There a heavy row simply is one long list of a wave task --
+    // every rating sees the one before it -- and the launch takes as long as that list; nobody times tiny problems.
+    if (cfg.waves_per_stripe <= 4 && cfg.task_steps <= 0) hot_len = 0x3FFFFFFF; // (an explicit task size keeps the workgroup tasks: tests)
+}
+
+void plan_hot_gathered(const PlanConfig &cfg, Plan &p)
+{
+    // A gathered row is read-modified-written by whatever lists hold one of its ratings at the moment; a row with more
+    // ratings in a block than one list holds is, on average, in several lists at once and loses most of its updates (and
+    // of its accumulator growth: its steps stay too large -- round 2 traced configs[2]'s -2 % to exactly these rows).
+    // EXPERIMENTAL (mfx_options.swap_heavy, off by default): such rows are taken out of the lock-free side -- their ratings
+    // are grouped by THEM and run in workgroup tasks with the roles swapped.  As long as those tasks run beside the wave
+    // tasks, an owner row that a wave task holds in registers is written back over what a swapped visit did to it
+    // meanwhile (order emulation, 20 k x 400 k case: +4.0 % against +1.0 % without), so this waits for a launch in two
+    // phases.  The test uses the row's global count (a block holds about 1/NS of it: the stripes have equal
+    // mass), so it can be made per rating before anything is sorted: swapped iff the gathered row is heavy and heavier
+    // than the rating's owner row.
+    int target, hot_len;
+    plan_sizes(p.nnz, p.ns * p.ns, p.groups, cfg, target, hot_len);
+    p.hot_len = hot_len;
+    p.waves_per_wg = std::max(1, std::min(4, cfg.waves_per_wg));
+    const std::vector<int> &og = p.owner_is_q ? p.omega_p : p.omega_q;
+    p.hot_gat.assign(og.size(), 0);
+    if (!cfg.swap_heavy) return;
+    const long long thr = (long long)hot_len * p.ns;
+    for (size_t i = 0; i < og.size(); ++i) p.hot_gat[i] = (long long)og[i] > thr ? 1 : 0;
 }
 
 void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig &cfg, Plan &p,
@@ -283,7 +377,8 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
     const int NS = p.ns, NB = NS * NS, G = p.groups;
     int target, hot_len;
     plan_sizes(p.nnz, NB, G, cfg, target, hot_len);
-    const bool timing = getenv("MFX_PLAN_TIMING") && atoi(getenv("MFX_PLAN_TIMING")) != 0;
+    const int W = p.waves_per_wg, waves = std::max(1, cfg.waves_per_stripe);
+    const bool timing = env_int_raw("MFX_PLAN_TIMING", 0) != 0;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;
@@ -291,32 +386,31 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
         fprintf(stderr, "mfx plan:   %-26s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
-    // Tasks per wave.  A block is cut into (tasks per wave) x (waves of its XCD) tasks of equal load
+    // Tasks per wave.  The ordinary rows of a block are cut into (tasks per wave) x (waves left to them) tasks of equal load
     // (longest-first packing), handed out through the block's cursor.  One task per wave -- every hand-over costs a
     // chain of misses, and longer lists keep the order closer to the reference's walk through a block (final RMSE
     // 0.4 .. 0.6 points closer to the oracle on configs[1] and configs[2] at no cost in time,
     // profiles/experiments/r02_tasks_per_wave.log) -- except for wide rows (k_a >= 128: two ratings per wave step) with a
     // long share per wave, where two tasks let the waves that run ahead take up the slack (3 .. 15 % of the epoch time;
-    // round 1: profiles/experiments/r01_task_sweep*.log).
-    // MFX_ONE_TASK=0 selects the older graded sizes (T, T/2, T/4, T/8 from task_steps).
-    const long long per_wave = p.nnz / ((long long)NB * G * std::max(1, cfg.waves_per_stripe));
-    const char *ot = getenv("MFX_ONE_TASK");
-    const int tasks_per_wave = ot && *ot ? atoi(ot) : cfg.task_steps > 0 ? 0 : (per_wave < 128 || G >= 4) ? 1 : 2;
-    const int one_task = tasks_per_wave * std::max(1, cfg.waves_per_stripe);
-    // combine slots: one per owner row that is cut into chains in some block (row -> slot, -1 = none)
-    std::vector<int> hot_slot((size_t)(p.owner_is_q ? p.n : p.m), -1);
+    // round 1: profiles/experiments/r01_task_sweep*.log).  An explicit task_steps (tests) selects tasks of that size.
+    const long long per_wave = p.nnz / ((long long)NB * G * waves);
+    const int tasks_per_wave = cfg.task_steps > 0 ? 0 : knob_int("MFX_ONE_TASK", (per_wave < 128 || G >= 4) ? 1 : 2);
+    // combine slots: one per row that is split over several workgroups in some block (row -> slot, -1 = none), both sides
+    const int n_own = p.owner_is_q ? p.n : p.m, n_gat = p.owner_is_q ? p.m : p.n;
+    std::vector<int> slot_own((size_t)n_own, -1), slot_gat((size_t)n_gat, -1);
     p.n_hot_slots = 0;
     p.hot_rows.clear();
     {
-        // rows cut in each block (found in parallel), numbered in block order, then visit order
-        std::vector<std::vector<uint32_t>> cut(NB);
+        std::vector<std::vector<uint32_t>> cut(NB); // row | side << 31
         std::atomic<int> nb(0);
         auto scan = [&]() {
             for (;;) {
                 const int b = nb.fetch_add(1);
                 if (b >= NB) break;
+                const long long T = block_steps_per_wave(block_visits[b], G, W, waves, hot_len);
                 for (const Visit &v : block_visits[b])
-                    if ((long long)v.len > hot_len) cut[b].push_back(v.own);
+                    if ((v.swapped || (long long)v.len > hot_len) && visit_copies(v.len, (long long)W * G, T) > 1)
+                        cut[b].push_back(v.own | (v.swapped ? 0x80000000u : 0u));
             }
         };
         std::vector<std::thread> pool;
@@ -324,18 +418,15 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
         for (int t = 0; t < nt; ++t) pool.emplace_back(scan);
         for (auto &th : pool) th.join();
         for (int b = 0; b < NB; ++b)
-            for (uint32_t own : cut[b])
-                if (hot_slot[own] < 0) {
-                    hot_slot[own] = (int)p.n_hot_slots++;
-                    p.hot_rows.push_back((int)own);
+            for (uint32_t key : cut[b]) {
+                int &sl = (key >> 31) ? slot_gat[key & 0x7FFFFFFFu] : slot_own[key & 0x7FFFFFFFu];
+                if (sl < 0) {
+                    sl = (int)p.n_hot_slots++;
+                    p.hot_rows.push_back((int)key);
                 }
+            }
     }
-    if (p.n_hot_slots >= (1 << 20) || hot_len >= (1 << 12))
-        throw std::invalid_argument("too many hot rows / too long chains for the header entry format");
-    // experiment knob: round 1's behaviour (chains overwrite the row, the last writer wins: no headers, no fold)
-    const char *lww = getenv("MFX_HOT_LWW");
-    const bool hot_lww = lww && *lww && atoi(lww) != 0;
-    lap("hot slots");
+    lap("combine slots");
     std::vector<BlockPack> packs(NB);
     {
         std::vector<int> blocks(NB);
@@ -344,34 +435,45 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
             return block_visits[a].size() > block_visits[b].size();
         });
         std::atomic<int> next(0);
+        std::exception_ptr first_error; // an exception must not leave a worker thread (std::terminate): rethrown after the join
+        std::mutex err_mu;
         auto work = [&]() {
             for (;;) {
                 int idx = next.fetch_add(1);
                 if (idx >= NB) break;
-                pack_visits(block_visits[blocks[idx]], G, target, hot_len, packs[blocks[idx]], one_task,
-                            hot_lww ? nullptr : &hot_slot);
+                try {
+                    pack_block(block_visits[blocks[idx]], G, W, waves, target, hot_len, tasks_per_wave, slot_own, slot_gat,
+                               packs[blocks[idx]]);
+                } catch (...) {
+                    std::lock_guard<std::mutex> lock(err_mu);
+                    if (!first_error) first_error = std::current_exception();
+                }
             }
         };
         std::vector<std::thread> pool;
         int nt = std::max(1, std::min(threads, NB));
         for (int t = 0; t < nt; ++t) pool.emplace_back(work);
         for (auto &th : pool) th.join();
+        if (first_error) std::rethrow_exception(first_error);
     }
     lap("pack blocks (threads)");
     // concatenate in (round, slot) order: round r, slot s -> owner stripe s,
     // gathered stripe (s + r) mod NS, so the NS slots of a round are stripe-disjoint
-    size_t tot_t = 0, tot_p = 0;
+    size_t tot_t = 0, tot_p = 0, tot_w = 0, tot_v = 0;
     for (auto &o : packs) {
         tot_t += o.tasks.size();
         tot_p += o.places.size();
+        tot_w += o.wg_tasks.size();
+        tot_v += o.wg_visits.size();
         p.n_hot_rows += o.hot;
         p.n_padding += o.padding;
     }
     p.round_hot.assign((size_t)NS, 0);
     p.slot_task_ptr.assign((size_t)NB + 1, 0);
+    p.slot_wg_ptr.assign((size_t)NB + 1, 0);
     // bases of every (round, slot) piece, then the pieces are copied side by side
     std::vector<uint64_t> e_base((size_t)NB + 1, 0);
-    std::vector<size_t> t_base((size_t)NB + 1, 0), p_base((size_t)NB + 1, 0), h_base((size_t)NB + 1, 0);
+    std::vector<size_t> t_base((size_t)NB + 1, 0), p_base((size_t)NB + 1, 0), w_base((size_t)NB + 1, 0), v_base((size_t)NB + 1, 0);
     for (int r = 0; r < NS; ++r)
         for (int s = 0; s < NS; ++s) {
             const BlockPack &o = packs[s * NS + (s + r) % NS];
@@ -379,13 +481,16 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
             e_base[i + 1] = e_base[i] + o.n_entries;
             t_base[i + 1] = t_base[i] + o.tasks.size();
             p_base[i + 1] = p_base[i] + o.places.size();
-            h_base[i + 1] = h_base[i] + o.headers.size();
-            if (!o.headers.empty()) p.round_hot[r] = 1;
+            w_base[i + 1] = w_base[i] + o.wg_tasks.size();
+            v_base[i + 1] = v_base[i] + o.wg_visits.size();
+            if (o.folds) p.round_hot[r] = 1;
             p.slot_task_ptr[i + 1] = (long long)t_base[i + 1];
+            p.slot_wg_ptr[i + 1] = (long long)w_base[i + 1];
         }
     p.tasks.resize(tot_t);
+    p.wg_tasks.resize(tot_w);
+    p.wg_visits.resize(tot_v);
     places.resize(tot_p);
-    p.headers.resize(h_base[NB]);
     {
         std::atomic<int> nb(0);
         auto copy = [&]() {
@@ -400,19 +505,22 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
                     td[j] = o.tasks[j];
                     td[j].off += eb;
                 }
+                WgTask *wt = p.wg_tasks.data() + w_base[i];
+                for (size_t j = 0; j < o.wg_tasks.size(); ++j) {
+                    wt[j] = o.wg_tasks[j];
+                    wt[j].off += eb;
+                    wt[j].visit0 += (uint32_t)v_base[i];
+                }
+                std::copy(o.wg_visits.begin(), o.wg_visits.end(), p.wg_visits.begin() + (long long)v_base[i]);
                 Placement *pl = places.data() + p_base[i];
                 for (size_t j = 0; j < o.places.size(); ++j) {
                     pl[j] = o.places[j];
                     pl[j].dst += eb;
                 }
-                HeaderRec *hd = p.headers.data() + h_base[i];
-                for (size_t j = 0; j < o.headers.size(); ++j) {
-                    hd[j] = o.headers[j];
-                    hd[j].dst += eb;
-                }
                 std::vector<TaskDesc>().swap(o.tasks);
                 std::vector<Placement>().swap(o.places);
-                std::vector<HeaderRec>().swap(o.headers);
+                std::vector<WgTask>().swap(o.wg_tasks);
+                std::vector<WgVisitRec>().swap(o.wg_visits);
             }
         };
         std::vector<std::thread> pool;
@@ -566,36 +674,42 @@ void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cf
         cnt_q[R[i].v]++;
     }
     plan_maps(cfg, p, cnt_p.data(), cnt_q.data());
+    plan_hot_gathered(cfg, p);
 
-    // relabel (shuffle_problem, mf.cpp:775-791), scale (mf.cpp:517-527) and bucket by block
+    // relabel (shuffle_problem, mf.cpp:775-791), scale (mf.cpp:517-527) and bucket by (block, role): the ratings of a
+    // heavy gathered row are keyed by that row first (plan_hot_gathered)
     const int *own_begin = p.owner_is_q ? p.q_begin.data() : p.p_begin.data();
     const int *gat_begin = p.owner_is_q ? p.p_begin.data() : p.q_begin.data();
+    const int *omega_own = p.owner_is_q ? p.omega_q.data() : p.omega_p.data();
+    const int *omega_gat = p.owner_is_q ? p.omega_p.data() : p.omega_q.data();
     std::vector<Rat> rat(nnz);
-    std::vector<uint16_t> blk(nnz);
+    std::vector<uint32_t> blk(nnz); // block * 2 + swapped
     const bool do_scale = p.inv_scale != 1.0f;
     parallel_ranges(nnz, threads, [&](long long b, long long e, int) {
         for (long long i = b; i < e; ++i) {
             uint32_t u = (uint32_t)p.p_map[R[i].u], v = (uint32_t)p.q_map[R[i].v];
+            const uint32_t own = p.owner_is_q ? v : u, gat = p.owner_is_q ? u : v;
+            const bool sw = p.hot_gat[gat] && omega_gat[gat] > omega_own[own];
             Rat x;
-            x.own = p.owner_is_q ? v : u;
-            x.gat = p.owner_is_q ? u : v;
+            x.own = sw ? gat : own;
+            x.gat = sw ? own : gat;
             x.r = do_scale ? R[i].r * p.inv_scale : R[i].r;
             rat[i] = x;
-            blk[i] = (uint16_t)(stripe_of(own_begin, NS, x.own) * NS + stripe_of(gat_begin, NS, x.gat));
+            blk[i] = (uint32_t)(stripe_of(own_begin, NS, own) * NS + stripe_of(gat_begin, NS, gat)) * 2u + (sw ? 1u : 0u);
         }
     });
-    std::vector<long long> bptr(NB + 1, 0);
+    std::vector<long long> bptr(2 * NB + 1, 0);
     for (long long i = 0; i < nnz; ++i) bptr[blk[i] + 1]++;
-    for (int b = 0; b < NB; ++b) bptr[b + 1] += bptr[b];
+    for (int b = 0; b < 2 * NB; ++b) bptr[b + 1] += bptr[b];
     std::vector<Rat> sorted(nnz);
     {
         std::vector<long long> cur(bptr.begin(), bptr.end() - 1);
         for (long long i = 0; i < nnz; ++i) sorted[cur[blk[i]]++] = rat[i];
     }
     std::vector<Rat>().swap(rat);
-    std::vector<uint16_t>().swap(blk);
+    std::vector<uint32_t>().swap(blk);
 
-    // per-block sort by (owner, gathered) -- stable, so equal pairs keep their input order, the
+    // per-bucket sort by (primary, secondary) -- stable, so equal pairs keep their input order, the
     // same order the device path's radix sort leaves them in -- and the visit table
     std::vector<std::vector<Visit>> block_visits(NB);
     {
@@ -604,17 +718,19 @@ void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cf
             for (;;) {
                 int b = next.fetch_add(1);
                 if (b >= NB) break;
-                Rat *beg = sorted.data() + bptr[b];
-                const long long L = bptr[b + 1] - bptr[b];
-                std::stable_sort(beg, beg + L, [](const Rat &x, const Rat &y) {
-                    return x.own != y.own ? x.own < y.own : x.gat < y.gat;
-                });
                 std::vector<Visit> &vs = block_visits[b];
-                for (long long i = 0; i < L;) {
-                    long long j = i;
-                    while (j < L && beg[j].own == beg[i].own) ++j;
-                    vs.push_back({beg[i].own, (uint32_t)(j - i), (uint64_t)(bptr[b] + i)});
-                    i = j;
+                for (int sw = 0; sw < 2; ++sw) {
+                    Rat *beg = sorted.data() + bptr[2 * b + sw];
+                    const long long L = bptr[2 * b + sw + 1] - bptr[2 * b + sw];
+                    std::stable_sort(beg, beg + L, [](const Rat &x, const Rat &y) {
+                        return x.own != y.own ? x.own < y.own : x.gat < y.gat;
+                    });
+                    for (long long i = 0; i < L;) {
+                        long long j = i;
+                        while (j < L && beg[j].own == beg[i].own) ++j;
+                        vs.push_back({beg[i].own, (uint32_t)(j - i), (uint64_t)(bptr[2 * b + sw] + i), (uint32_t)sw});
+                        i = j;
+                    }
                 }
             }
         };
@@ -627,23 +743,24 @@ void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cf
     PlaceVec places;
     finish_plan(block_visits, cfg, p, places, threads);
 
-    // write the entries: a placement puts `len` consecutive sorted ratings into one lane-group
-    // list (stride G), the first one flagged "owner row changes here"
+    // write the entries: a placement puts `len` sorted ratings (stride apart) into one lane-group list (stride G)
     p.entries.assign((size_t)p.n_entries, Entry{0u, -1, 0.0f});
     const int G = p.groups;
     parallel_ranges((long long)places.size(), threads, [&](long long b, long long e, int) {
         for (long long i = b; i < e; ++i) {
             const Placement &pl = places[i];
+            const uint32_t stride = pl.stride_flags & 0xFFFFu;
+            const uint32_t flags = (pl.stride_flags >> 31) ? ENTRY_SWAPPED : 0u;
+            const bool visit_start = ((pl.stride_flags >> 30) & 1u) != 0;
             for (uint32_t x = 0; x < pl.len; ++x) {
-                const Rat &rr = sorted[pl.src + x];
+                const Rat &rr = sorted[pl.src + (uint64_t)x * stride];
                 Entry &en = p.entries[pl.dst + (uint64_t)x * G];
-                en.own = rr.own | (x == 0 ? 0x80000000u : 0u);
+                en.own = rr.own | flags | ((visit_start && x == 0) ? 0x80000000u : 0u);
                 en.gat = (int32_t)rr.gat;
                 en.r = rr.r;
             }
         }
     });
-    for (const HeaderRec &h : p.headers) p.entries[h.dst] = header_entry(h);
 }
 
 void init_factors(const Plan &p, const int *omega_p_override, const int *omega_q_override,

@@ -21,27 +21,42 @@ struct Node { int u; int v; float r; }; // = mf_node (reference mf/mf.h:36-41)
 // One rating as the kernel reads it.  `own` = id on the register-resident ("owner")
 // side, bit 31 set when the owner row must be (re)loaded before this rating;
 // `gat` = id on the gathered side, -1 for a padding slot.
+// In a workgroup task (below) `own` is the heavy row the visit belongs to; bit 30 (ENTRY_SWAPPED) says that this
+// row lives on the plan's GATHERED side -- `own` then indexes the gathered side's factors and `gat` the owner side's.
 struct Entry { uint32_t own; int32_t gat; float r; };
+constexpr uint32_t ENTRY_SWAPPED = 0x40000000u, ENTRY_ID_MASK = 0x3FFFFFFFu;
 static_assert(sizeof(Entry) == 12, "Entry must stay 12 bytes (mf_node sized)");
 
 // One wavefront task: `nsteps` steps of G = 64/lanes ratings, stored step-major
 // (entry index = off + step*G + group).
 struct TaskDesc { uint64_t off; uint32_t nsteps; uint32_t pad; };
 
-// All ratings of one owner row inside one block: `len` consecutive ratings of the block-sorted
-// rating array, starting at global index `start`.  A visit longer than the hot-chain length is cut into
-// `nch` chains (nch = 0: an ordinary visit); `hot` is then the row's combine slot (Plan::n_hot_slots).
-struct Visit { uint32_t own; uint32_t len; uint64_t start; uint32_t nch = 0; uint32_t hot = 0; uint32_t idx = 0; };
+// All ratings of one row inside one block: `len` consecutive ratings of the block-sorted rating array, starting at
+// global index `start`.  swapped = 0: a row of the plan's owner side (the ratings are sorted by it); swapped = 1: a heavy
+// row of the GATHERED side whose ratings were taken out of the owner-major order and grouped by that row instead.
+struct Visit { uint32_t own; uint32_t len; uint64_t start; uint32_t swapped = 0; };
 
-// Header entry of a hot chain (written into the entry stream just before the chain's first rating):
-// entries[dst] = {own | bit 31, -(1 + (nch | idx << 15)), bits of `hot`}: nch chains of this row in this block
-// (2 <= nch < 2^15), this one is number idx in the order of the sorted visit; hot = combine slot (bits 0..19) |
-// chain length << 20.  The kernel gives every chain of a hot row its
-// own register copy and folds the chains' changes together when the last one of the launch ends.
-struct HeaderRec { uint64_t dst; uint32_t own; uint32_t nch; uint32_t hot; uint32_t idx; };
+// ---- workgroup tasks: the heavy rows ----
+// A row with more ratings in a block than one list should hold (hot_len) is not cut into independent chains any more
+// (rounds 1-2: private register copies folded by a calibrated model).  Its ratings are dealt over ALL lists of one
+// workgroup -- W waves x G lane groups advance through them side by side -- and the row lives in LDS for the length of that
+// visit, updated by every list with LDS float atomics: one copy, no lost update, the sequential meaning of the order up
+// to the 4 x G ratings in flight.  Only a row with more ratings than one workgroup does in a launch is split over several
+// workgroups (n_copies > 1); those copies add their change to the row's combine slot and fold_hot_rows folds them.
+// Heavy rows of the gathered side get the same treatment with the roles swapped, instead of being read-modified-written
+// by hundreds of lists at once (where most of their updates were lost).
+//
+// A workgroup task = `nvisits` visits run one after the other; its entries are stored wave-major (wave w of the
+// workgroup streams entries [off + w*nsteps*G, off + (w+1)*nsteps*G), step-major like a wave task), the visits tile the
+// steps [0, nsteps).  All visits of a task have the same role (info bit 0).
+struct WgVisit { uint32_t row; uint32_t nsteps; uint32_t len; uint32_t info; }; // info: n_copies << 1 | swapped; slot in `slot`
+struct WgVisitRec { WgVisit v; uint32_t slot; uint32_t pad; };                  // 24 bytes, what the kernel reads
+struct WgTask { uint64_t off; uint32_t nsteps; uint32_t visit0; uint32_t nvisits; uint32_t swapped; };
+static_assert(sizeof(WgVisitRec) == 24 && sizeof(WgTask) == 24, "kernel-visible layouts");
 
-// "Put sorted ratings [src, src+len) into entries[dst + x*G], x = 0..len-1, the first one flagged."
-struct Placement { uint64_t src; uint64_t dst; uint32_t len; uint32_t pad; };
+// "Put sorted ratings src, src+stride, ... (len of them) into entries[dst + x*G], x = 0..len-1."  Bit 30: the visit of a
+// wave task, whose first entry is flagged "owner row changes here"; bit 31: a list of a workgroup visit with the roles swapped.
+struct Placement { uint64_t src; uint64_t dst; uint32_t len; uint32_t stride_flags; }; // stride (bits 0..15) | flags
 // vector whose resize() leaves trivially constructible elements uninitialised: the merged placement list of a plan is
 // ~100 MB at 100 M ratings and is filled by several threads, which should also be the ones to touch its pages first
 template <class T> struct DefaultInitAlloc : std::allocator<T> {
@@ -54,10 +69,12 @@ typedef std::vector<Placement, DefaultInitAlloc<Placement>> PlaceVec;
 // Result of packing one block; entry offsets are relative to the block.
 struct BlockPack {
     std::vector<TaskDesc> tasks;
+    std::vector<WgTask> wg_tasks;       // visit0 relative to wg_visits
+    std::vector<WgVisitRec> wg_visits;
     std::vector<Placement> places;
-    std::vector<HeaderRec> headers;
     uint64_t n_entries = 0;
     long long hot = 0, padding = 0;
+    bool folds = false;                 // some row of this block is split over several workgroups
 };
 
 struct PlanConfig {
@@ -73,6 +90,8 @@ struct PlanConfig {
     bool use_stats = false;   // take avg/std from below instead of collect_info
     float stats_avg = 0, stats_std = 0;
     int waves_per_stripe = 256; // for auto task sizing
+    int waves_per_wg = 4;     // waves of a workgroup that take work (W of a workgroup task)
+    bool swap_heavy = false;  // also run the heavy rows of the GATHERED side in workgroup tasks, roles swapped (experimental)
     int threads = 0;          // host worker threads, 0 = hardware_concurrency
 };
 
@@ -92,26 +111,19 @@ struct Plan {
     std::vector<Entry> entries;
     std::vector<TaskDesc> tasks;
     std::vector<long long> slot_task_ptr; // ns*ns+1, ordered (round, slot)
-    std::vector<HeaderRec> headers;       // hot-chain header entries (already part of `entries` on the host path)
-    long long n_hot_slots = 0;            // distinct rows that are cut into chains somewhere
-    std::vector<int> hot_rows;            // combine slot -> internal owner row
-    std::vector<char> round_hot;          // ns flags: does round r hold any chain (is there anything to fold behind it)?
+    std::vector<WgTask> wg_tasks;         // workgroup tasks, ordered like the wave tasks
+    std::vector<WgVisitRec> wg_visits;
+    std::vector<long long> slot_wg_ptr;   // ns*ns+1
+    int waves_per_wg = 4;
+    int hot_len = 128;                    // a row with more ratings in a block goes to a workgroup task
+    std::vector<char> hot_gat;            // per internal row of the gathered side: heavy by its global count (roles swapped)
+    long long n_hot_slots = 0;            // rows that are split over several workgroups somewhere (combine slots)
+    std::vector<int> hot_rows;            // combine slot -> internal row | side << 31 (1 = gathered side of the plan)
+    std::vector<char> round_hot;          // ns flags: does round r hold a split row (is there anything to fold behind it)?
     long long n_entries = 0;   // entries.size() on the host path; on the device path the array lives in HBM only
     long long n_hot_rows = 0;
     long long n_padding = 0;
 };
-
-// the entry a header record stands for
-inline Entry header_entry(const HeaderRec &h)
-{
-    Entry e;
-    e.own = h.own | 0x80000000u;
-    e.gat = -(int32_t)(1u + (h.nch | (h.idx << 15))); // <= -3: nch >= 2 (a pad slot is -1)
-    uint32_t bits = h.hot;
-    static_assert(sizeof(float) == 4, "");
-    __builtin_memcpy(&e.r, &bits, 4);
-    return e;
-}
 
 // pieces shared by the host builder (build_plan) and the device builder (prep.hip)
 void plan_header(long long nnz, int m, int n, const PlanConfig &cfg, Plan &p);
@@ -132,8 +144,10 @@ inline int stripe_of(const int *begin, int ns, unsigned id)
     }
     return lo;
 }
-void pack_visits(std::vector<Visit> &visits, int G, int target, int hot_len, BlockPack &out,
-                 int one_task_waves = 0, const std::vector<int> *hot_slot_of_row = nullptr);
+// task sizes of a plan: wave-task target and the length beyond which a row goes to a workgroup task
+void plan_sizes(long long nnz, int NB, int G, const PlanConfig &cfg, int &target, int &hot_len);
+// which rows of the gathered side are heavy enough to be taken out of the lock-free side (cnt = ratings per INTERNAL row)
+void plan_hot_gathered(const PlanConfig &cfg, Plan &p);
 void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig &cfg, Plan &p,
                  PlaceVec &places, int threads);
 

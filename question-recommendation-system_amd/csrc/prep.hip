@@ -8,9 +8,10 @@
 // packing of visits into tasks (plan.cpp: finish_plan) runs on the host, the entries are written
 // by a kernel.
 //
-//   ratings --key_build--> (block|own|gat) keys, scaled r, row counts
-//           --radix sort (hipCUB)--> block-major, owner-major order
-//           --run-length encode on (block|own)--> visit table --D2H--> finish_plan (host)
+//   ratings --key_build--> (block|role|primary|secondary) keys, scaled r, row counts
+//           (primary = owner id, or -- role "swapped" -- the id of a heavy gathered row: plan_hot_gathered)
+//           --radix sort (hipCUB)--> block-major, primary-major order
+//           --run-length encode on (block|role|primary)--> visit table --D2H--> finish_plan (host)
 //           --H2D placements--> emit_entries --> entries[] in HBM
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -117,11 +118,13 @@ __global__ __launch_bounds__(256) void stats_kernel(const Node *R, long long nnz
     }
 }
 
-// relabel, scale, count rows, build the sort key (block | owner id | gathered id)
+// relabel, scale, count rows, build the sort key (block | role | primary id | secondary id)
 // bounds: own_begin[ns+1] then gat_begin[ns+1] (internal-id boundaries of the stripes)
+// omega_own / omega_gat: ratings per internal row; hot_gat: heavy rows of the gathered side (plan_hot_gathered)
 __global__ __launch_bounds__(256) void key_build(const Node *R, long long nnz, const int *p_map,
                                                  const int *q_map, int owner_is_q, float inv_scale,
-                                                 int do_scale, const int *bounds, int ns,
+                                                 int do_scale, const int *bounds, int ns, const int *omega_own,
+                                                 const int *omega_gat, const char *hot_gat,
                                                  unsigned long long *keys, float *vals)
 {
     __shared__ int sb[2 * 257];
@@ -136,12 +139,14 @@ __global__ __launch_bounds__(256) void key_build(const Node *R, long long nnz, c
         const unsigned own = owner_is_q ? v : u, gat = owner_is_q ? u : v;
         const unsigned long long blk =
             (unsigned long long)stripe_of(own_begin, ns, own) * ns + stripe_of(gat_begin, ns, gat);
-        keys[i] = (blk << (2 * ID_BITS)) | ((unsigned long long)own << ID_BITS) | gat;
+        const bool sw = hot_gat[gat] && omega_gat[gat] > omega_own[own];
+        keys[i] = (blk << (2 * ID_BITS + 1)) | ((unsigned long long)(sw ? 1 : 0) << (2 * ID_BITS)) |
+                  ((unsigned long long)(sw ? gat : own) << ID_BITS) | (sw ? own : gat);
         vals[i] = do_scale ? x.r * inv_scale : x.r;
     }
 }
 
-struct VisitKey { // (block | owner) part of a sort key
+struct VisitKey { // (block | role | primary) part of a sort key
     __host__ __device__ unsigned long long operator()(unsigned long long k) const { return k >> ID_BITS; }
 };
 
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256) void fill_entries(EntryD *e, long long n)
     for (long long i = tid; i < n; i += nth) e[i] = EntryD{0u, -1, 0.0f};
 }
 
-// one lane per placement chunk: entries[dst + x*G] <- sorted rating src+x
+// one lane per placement: entries[dst + x*G] <- sorted rating src + x*stride (plan.hpp: Placement)
 __global__ __launch_bounds__(256) void emit_entries(const Placement *pl, long long npl,
                                                     const unsigned long long *keys, const float *vals,
                                                     int G, EntryD *entries)
@@ -161,29 +166,17 @@ __global__ __launch_bounds__(256) void emit_entries(const Placement *pl, long lo
     const long long nth = (long long)gridDim.x * blockDim.x;
     for (long long i = tid; i < npl; i += nth) {
         const Placement p = pl[i];
+        const unsigned stride = p.stride_flags & 0xFFFFu;
+        const unsigned flags = (p.stride_flags >> 31) ? ENTRY_SWAPPED : 0u;
+        const bool visit_start = ((p.stride_flags >> 30) & 1u) != 0;
         for (unsigned x = 0; x < p.len; ++x) {
-            const unsigned long long k = keys[p.src + x];
+            const unsigned long long k = keys[p.src + (unsigned long long)x * stride];
             EntryD e;
-            e.own = (unsigned)((k >> ID_BITS) & ((1u << ID_BITS) - 1)) | (x == 0 ? 0x80000000u : 0u);
+            e.own = (unsigned)((k >> ID_BITS) & ((1u << ID_BITS) - 1)) | flags | ((visit_start && x == 0) ? 0x80000000u : 0u);
             e.gat = (int)(k & ((1u << ID_BITS) - 1));
-            e.r = vals[p.src + x];
+            e.r = vals[p.src + (unsigned long long)x * stride];
             entries[p.dst + (unsigned long long)x * G] = e;
         }
-    }
-}
-
-// header entries of the hot chains (plan.hpp: HeaderRec)
-__global__ __launch_bounds__(256) void emit_headers(const HeaderRec *h, long long nh, EntryD *entries)
-{
-    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long nth = (long long)gridDim.x * blockDim.x;
-    for (long long i = tid; i < nh; i += nth) {
-        const HeaderRec r = h[i];
-        EntryD e;
-        e.own = r.own | 0x80000000u;
-        e.gat = -(int)(1u + (r.nch | (r.idx << 15)));
-        e.r = __uint_as_float(r.hot);
-        entries[r.dst] = e;
     }
 }
 
@@ -341,15 +334,26 @@ void build_plan_device(const void *dR_v, long long nnz, int m, int n, const Plan
     lap("stats + counts");
     // id maps, stripe boundaries, omega (host: the glibc-compatible shuffle is serial)
     plan_maps(cfg, p, cnt_p.data(), cnt_q.data());
+    plan_hot_gathered(cfg, p);
     lap("id maps (host)");
 
     // 2. keys
-    Buf<int> dPmap, dQmap, dBounds;
+    Buf<int> dPmap, dQmap, dBounds, dOmOwn, dOmGat;
+    Buf<char> dHotGat;
     dPmap.alloc(m);
     dQmap.alloc(n);
     dBounds.alloc(2 * (NS + 1));
     PREP_TRY(hipMemcpyAsync(dPmap.p, p.p_map.data(), (size_t)m * 4, hipMemcpyHostToDevice, s));
     PREP_TRY(hipMemcpyAsync(dQmap.p, p.q_map.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    {
+        const std::vector<int> &oo = p.owner_is_q ? p.omega_q : p.omega_p, &og = p.owner_is_q ? p.omega_p : p.omega_q;
+        dOmOwn.alloc(oo.size());
+        dOmGat.alloc(og.size());
+        dHotGat.alloc(p.hot_gat.size());
+        PREP_TRY(hipMemcpyAsync(dOmOwn.p, oo.data(), oo.size() * 4, hipMemcpyHostToDevice, s));
+        PREP_TRY(hipMemcpyAsync(dOmGat.p, og.data(), og.size() * 4, hipMemcpyHostToDevice, s));
+        PREP_TRY(hipMemcpyAsync(dHotGat.p, p.hot_gat.data(), p.hot_gat.size(), hipMemcpyHostToDevice, s));
+    }
     {
         const std::vector<int> &ob = p.owner_is_q ? p.q_begin : p.p_begin, &gb = p.owner_is_q ? p.p_begin : p.q_begin;
         PREP_TRY(hipMemcpyAsync(dBounds.p, ob.data(), (size_t)(NS + 1) * 4, hipMemcpyHostToDevice, s));
@@ -363,13 +367,15 @@ void build_plan_device(const void *dR_v, long long nnz, int m, int n, const Plan
     dValB.alloc(nnz);
     lap("maps H2D + key buffers");
     hipLaunchKernelGGL(key_build, dim3(grid_of(nnz, cu_count)), dim3(256), 0, s, dR, nnz, dPmap.p, dQmap.p,
-                       p.owner_is_q ? 1 : 0, p.inv_scale, p.inv_scale != 1.0f ? 1 : 0, dBounds.p, NS, dKeyA.p, dValA.p);
+                       p.owner_is_q ? 1 : 0, p.inv_scale, p.inv_scale != 1.0f ? 1 : 0, dBounds.p, NS, dOmOwn.p, dOmGat.p,
+                       dHotGat.p, dKeyA.p, dValA.p);
 
     lap("keys");
     // 3. sort by (block, owner, gathered); stable, so equal pairs keep their input order
     int blk_bits = 1;
     while ((1 << blk_bits) < NB) ++blk_bits;
-    const int end_bit = 2 * ID_BITS + blk_bits;
+    const int end_bit = 2 * ID_BITS + 1 + blk_bits;
+    if (end_bit > 64) throw std::invalid_argument("too many stripes for the device builder's sort key");
     size_t tmp_bytes = 0;
     PREP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, dKeyA.p, dKeyB.p, dValA.p, dValB.p, nnz, 0, end_bit, s));
     Buf<char> dTmp;
@@ -403,9 +409,10 @@ void build_plan_device(const void *dR_v, long long nnz, int m, int n, const Plan
     std::vector<std::vector<Visit>> block_visits(NB);
     {
         // the runs are sorted by block: every block is one range of them, filled by its own thread
+        // (run key = block << (ID_BITS + 1) | role << ID_BITS | primary id)
         std::vector<size_t> first((size_t)NB + 1, (size_t)runs);
         for (int b = 0; b <= NB; ++b) {
-            const unsigned long long key = (unsigned long long)b << ID_BITS;
+            const unsigned long long key = (unsigned long long)b << (ID_BITS + 1);
             first[b] = (size_t)(std::lower_bound(run_key.begin(), run_key.end(), key) - run_key.begin());
         }
         std::vector<uint64_t> start_of((size_t)NB + 1, 0); // sorted position of a block's first rating
@@ -427,7 +434,8 @@ void build_plan_device(const void *dR_v, long long nnz, int m, int n, const Plan
                 bv.reserve(first[b + 1] - first[b]);
                 uint64_t start = start_of[b];
                 for (size_t i = first[b]; i < first[b + 1]; ++i) {
-                    bv.push_back({(uint32_t)(run_key[i] & ((1u << ID_BITS) - 1)), (uint32_t)run_len[i], start});
+                    bv.push_back({(uint32_t)(run_key[i] & ((1u << ID_BITS) - 1)), (uint32_t)run_len[i], start,
+                                  (uint32_t)((run_key[i] >> ID_BITS) & 1u)});
                     start += (uint64_t)run_len[i];
                 }
             }
@@ -461,13 +469,6 @@ void build_plan_device(const void *dR_v, long long nnz, int m, int n, const Plan
         hipLaunchKernelGGL(fill_entries, dim3(grid_of(p.n_entries, cu_count)), dim3(256), 0, s, dEntries, p.n_entries);
         hipLaunchKernelGGL(emit_entries, dim3(grid_of((long long)places.size(), cu_count)), dim3(256), 0, s,
                            dPlaces.p, (long long)places.size(), dKeyB.p, dValB.p, G, dEntries);
-        Buf<HeaderRec> dHeaders;
-        if (!p.headers.empty()) {
-            dHeaders.alloc(p.headers.size());
-            PREP_TRY(hipMemcpyAsync(dHeaders.p, p.headers.data(), p.headers.size() * sizeof(HeaderRec), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(emit_headers, dim3(grid_of((long long)p.headers.size(), cu_count)), dim3(256), 0, s,
-                               dHeaders.p, (long long)p.headers.size(), dEntries);
-        }
         PREP_TRY(hipGetLastError());
         PREP_TRY(hipStreamSynchronize(s));
         lap("placements H2D + entries");

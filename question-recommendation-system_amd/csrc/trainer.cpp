@@ -21,6 +21,7 @@
 
 #include "../../include/mfx.h"
 #include "kernels.hpp"
+#include "knobs.hpp"
 #include "plan.hpp"
 #include "prep.hpp"
 #include "synth.hpp"
@@ -42,17 +43,17 @@ int fail(int code, const std::string &msg)
             return fail(MFX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
     } while (0)
 
-int env_int(const char *name, int dflt)
+// documented product switches (knobs.hpp), each read once per process
+int product_switch(const char *name, int dflt)
 {
-    const char *s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
+    return mfx::env_int_raw(name, dflt);
 }
-
-float env_flt(const char *name, float dflt)
-{
-    const char *s = getenv(name);
-    return (s && *s) ? (float)atof(s) : dflt;
-}
+const int g_host_plan = product_switch("MFX_HOST_PLAN", 0);
+const int g_host_init = product_switch("MFX_HOST_INIT", 0);
+const int g_host_threads = product_switch("MFX_HOST_THREADS", 0);
+const int g_plan_timing = product_switch("MFX_PLAN_TIMING", 0);
+const int g_predict_cache = product_switch("MFX_PREDICT_CACHE", 0);
+using mfx::knob_int; // experiment knobs: constants unless the library is built with -DMFX_EXPERIMENTS
 
 template <class T> struct DevBuf {
     T *p = nullptr;
@@ -103,10 +104,16 @@ struct mfx_trainer {
     DevBuf<mfx::EntryD> dEntries;
     DevBuf<mfx::TaskDescD> dTasks;
     DevBuf<long long> dSlotPtr;
-    DevBuf<double> dEpochState; // zeroed once per epoch: LOSS_SLOTS loss sums, then the ns*ns task cursors
+    DevBuf<mfx::WgTaskD> dWgTasks;   // workgroup tasks (heavy rows) and their visits
+    DevBuf<mfx::WgVisitD> dWgVisits;
+    DevBuf<long long> dSlotWgPtr;
+    long long n_wg_tasks = 0, n_wg_visits = 0;
+    DevBuf<double> dEpochState; // zeroed once per epoch: LOSS_SLOTS loss sums, then 2 * ns*ns cursors (wave tasks, workgroup tasks)
     int *dSlotStateP = nullptr;  // -> the cursors inside dEpochState
-    DevBuf<float> dHotAcc;   // combine slots of the hot rows (kernels.hip "hot chains")
-    DevBuf<int> dHotRow;     // combine slot -> internal owner row
+    DevBuf<float> dHotAcc;   // combine slots of the rows split over several workgroups (kernels.hip: fold_hot_rows)
+    DevBuf<int> dHotRow;     // combine slot -> internal row | side << 31
+    float max_wg_per_cu = 0;     // launch width that was chosen (for mfx_info)
+    int warm = 0;
     DevBuf<int> dSticky;     // raised by epoch_reset when an epoch left a block unfinished; never cleared
     DevBuf<double> dScalars; // [0..3] scratch for metrics
     double *dLossP = nullptr;    // -> the loss sums inside dEpochState
@@ -165,16 +172,16 @@ static int wgs_per_xcd_for(const mfx_options &opt, int m, int n, int ns, int cu_
 {
     *waves_per_wg = 4;
     if (opt.wg_per_cu > 0) return opt.wg_per_cu * cu_per_xcd;
-    int env = env_int("MFX_WG_PER_CU", 0);
+    int env = knob_int("MFX_WG_PER_CU", 0);
     if (env > 0) return env * cu_per_xcd;
-    env = env_int("MFX_WGS_PER_XCD", 0); // experiment knob: exact launch width (1 = four waves per XCD)
+    env = knob_int("MFX_WGS_PER_XCD", 0); // experiment knob: exact launch width (1 = four waves per XCD)
     if (env > 0) return env;
     const int ka = mfx::k_aligned(opt.k);
     const int G = 64 / mfx::lanes_for(ka);
     const bool owner_is_q = opt.owner_side == 0 ? (m >= n) : opt.owner_side == 2;
     const long long n_gat = owner_is_q ? m : n;
     const long long stripe_rows = (n_gat + ns - 1) / ns;
-    const int div = std::max(1, env_int("MFX_CONFLICT_DIV", 12));
+    const int div = std::max(1, knob_int("MFX_CONFLICT_DIV", 12));
     long long waves = stripe_rows / ((long long)div * G);
     // Small stripes: the head of the popularity distribution weighs more the fewer rows share a
     // stripe, and the RMSE gap to the sequential reference grows (+2.0..2.9 % at 2500 rows per stripe,
@@ -189,31 +196,21 @@ static int wgs_per_xcd_for(const mfx_options &opt, int m, int n, int ns, int cu_
     // Occupancy cap: about 64 ratings in flight per CU (2 workgroups of 4 waves at 8 ratings per wave).
     // The step is bound by instruction issue once a SIMD holds two waves; more waves only shorten the
     // tasks and crowd the L2 (sweep: profiles/experiments/r01_occupancy_sweep.log).
-    const long long cap = (long long)cu_per_xcd * std::max(1, env_int("MFX_MAX_WG_PER_CU", std::max(1, 16 / G)));
+    const long long cap = (long long)cu_per_xcd * std::max(1, knob_int("MFX_MAX_WG_PER_CU", std::max(1, 16 / G)));
     if (wgs > cap) wgs = cap;
     if (wgs < 1) wgs = 1;
     return (int)wgs;
 }
 
-// Stripes per side (= launches per epoch) and the launch width that goes with them.
-// Round 1 took half the stripes for small problems (a wave with fewer than 32 steps per launch: half the XCDs at work, a quarter
-// of the launches, four times the block -- one rank of N=8: 1.97 -> 1.46 ms per epoch).  It costs parity: with four times
-// the block a heavy row has four times the chains per fold and half the folds per epoch, and the damped fold then under-moves
-// it (slot trainer of 1.25 M ratings, 20 epochs, order emulation: +3.4 % with 4 stripes, +0.7 % with 8; four ranks on one
-// GPU against the oracle on the union problem: +4.8 % vs +0.5 %).  MFX_HALF_STRIPES=1 brings the rule back for experiments.
+// Stripes per side (= launches per epoch) and the launch width that goes with them: one stripe per XCD, whatever the size
+// of the problem.  (Round 1 took half the stripes for small problems; it cost parity -- four times the block means four
+// times the split of a heavy row and half the folds per epoch -- and is gone.)
 static int choose_stripes(const mfx_options &opt, long long nnz, int m, int n, int xcd_count, int cu_per_xcd,
                           int *wgs_per_xcd, int *waves_per_wg)
 {
-    int stripes = opt.stripes > 0 ? opt.stripes : std::max(1, env_int("MFX_STRIPES", xcd_count));
+    (void)nnz;
+    int stripes = opt.stripes > 0 ? opt.stripes : std::max(1, knob_int("MFX_STRIPES", xcd_count));
     *wgs_per_xcd = wgs_per_xcd_for(opt, m, n, stripes, cu_per_xcd, waves_per_wg);
-    if (env_int("MFX_HALF_STRIPES", 0) != 0 && opt.stripes <= 0 && env_int("MFX_STRIPES", 0) <= 0 && stripes >= 8) {
-        const int G = 64 / mfx::lanes_for(mfx::k_aligned(opt.k));
-        const long long waves = (long long)*wgs_per_xcd * *waves_per_wg;
-        if (nnz / ((long long)stripes * stripes * G * std::max<long long>(1, waves)) < 32) {
-            stripes /= 2;
-            *wgs_per_xcd = wgs_per_xcd_for(opt, m, n, stripes, cu_per_xcd, waves_per_wg);
-        }
-    }
     return stripes;
 }
 
@@ -223,15 +220,17 @@ static mfx::PlanConfig plan_config(const mfx_options &opt, int stripes, int wgs_
     cfg.k = opt.k;
     cfg.stripes = stripes;
     cfg.lanes = mfx::lanes_for(mfx::k_aligned(opt.k));
-    cfg.task_steps = opt.task_steps > 0 ? opt.task_steps : env_int("MFX_TASK_STEPS", 0);
+    cfg.task_steps = opt.task_steps > 0 ? opt.task_steps : knob_int("MFX_TASK_STEPS", 0);
     cfg.owner_side = opt.owner_side;
     // 0 mass-balanced stripes, 1 identity, 2 the reference's shuffle; an explicit option wins over the experiment knob
-    cfg.map_mode = opt.identity_maps != 0 ? opt.identity_maps : env_int("MFX_MAP_MODE", 0);
+    cfg.map_mode = opt.identity_maps != 0 ? opt.identity_maps : knob_int("MFX_MAP_MODE", 0);
     cfg.use_stats = opt.use_stats != 0;
     cfg.stats_avg = opt.stats_avg;
     cfg.stats_std = opt.stats_std;
     cfg.waves_per_stripe = wgs_per_xcd * waves_per_wg;
-    cfg.threads = env_int("MFX_HOST_THREADS", 0);
+    cfg.waves_per_wg = waves_per_wg;
+    cfg.swap_heavy = opt.swap_heavy != 0 || knob_int("MFX_SWAP_HEAVY", 0) != 0;
+    cfg.threads = g_host_threads;
     return cfg;
 }
 
@@ -300,9 +299,9 @@ static int create_impl(const mfx::Node *R, const void *R_dev, long long nnz, int
 
     // Pre-processing: on the device (prep.hip) unless forced to the host builder (MFX_HOST_PLAN=1)
     // or the ids do not fit the sort key.  R may be host memory (uploaded once) or already in HBM.
-    const bool device_plan = env_int("MFX_HOST_PLAN", 0) == 0 && mfx::device_prep_supported(m, n);
+    const bool device_plan = g_host_plan == 0 && mfx::device_prep_supported(m, n);
     mfx::EntryD *dev_entries = nullptr;
-    const bool plan_timing = env_int("MFX_PLAN_TIMING", 0) != 0;
+    const bool plan_timing = g_plan_timing != 0;
     const auto t_create = std::chrono::steady_clock::now();
     auto since = [&](const char *what) {
         if (plan_timing)
@@ -356,6 +355,8 @@ static int create_impl(const mfx::Node *R, const void *R_dev, long long nnz, int
     t->rk1 = (opt.rk_mode == 1 && p.ka > 8) ? (float)1.0 / (p.ka - 8) : 0.125f;
     t->n_entries = dev_entries ? p.n_entries : (long long)p.entries.size();
     t->n_tasks = (long long)p.tasks.size();
+    t->n_wg_tasks = (long long)p.wg_tasks.size();
+    t->n_wg_visits = (long long)p.wg_visits.size();
 
     int rc = MFX_OK;
     auto up = [&]() -> int {
@@ -364,7 +365,16 @@ static int create_impl(const mfx::Node *R, const void *R_dev, long long nnz, int
         else HIP_TRY(t->dEntries.alloc(p.entries.size()));
         HIP_TRY(t->dTasks.alloc(p.tasks.size()));
         HIP_TRY(t->dSlotPtr.alloc(p.slot_task_ptr.size()));
-        const size_t epoch_state_doubles = mfx::LOSS_SLOTS + ((size_t)p.ns * p.ns + 1) / 2;
+        static_assert(sizeof(mfx::WgTask) == sizeof(mfx::WgTaskD) && sizeof(mfx::WgVisitRec) == sizeof(mfx::WgVisitD), "plan.hpp <-> kernels.hpp");
+        HIP_TRY(t->dWgTasks.alloc(std::max<size_t>(1, p.wg_tasks.size())));
+        HIP_TRY(t->dWgVisits.alloc(std::max<size_t>(1, p.wg_visits.size())));
+        HIP_TRY(t->dSlotWgPtr.alloc(p.slot_wg_ptr.size()));
+        if (!p.wg_tasks.empty())
+            HIP_TRY(hipMemcpy(t->dWgTasks.p, p.wg_tasks.data(), p.wg_tasks.size() * sizeof(mfx::WgTask), hipMemcpyHostToDevice));
+        if (!p.wg_visits.empty())
+            HIP_TRY(hipMemcpy(t->dWgVisits.p, p.wg_visits.data(), p.wg_visits.size() * sizeof(mfx::WgVisitRec), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t->dSlotWgPtr.p, p.slot_wg_ptr.data(), p.slot_wg_ptr.size() * sizeof(long long), hipMemcpyHostToDevice));
+        const size_t epoch_state_doubles = mfx::LOSS_SLOTS + (size_t)p.ns * p.ns + 1;
         HIP_TRY(t->dEpochState.alloc(epoch_state_doubles));
         HIP_TRY(hipMemset(t->dEpochState.p, 0, epoch_state_doubles * sizeof(double)));
         t->dLossP = t->dEpochState.p;
@@ -383,11 +393,12 @@ static int create_impl(const mfx::Node *R, const void *R_dev, long long nnz, int
         HIP_TRY(t->dSticky.alloc(1));
         HIP_TRY(hipMemset(t->dSticky.p, 0, sizeof(int)));
         {
-            // stripe boundaries for the kernel (buffer descriptors over the gathered stripe, L2 warm-up)
+            // stripe boundaries for the kernel (buffer descriptors over the stripe that is read-modified-written, L2 warm-up)
             const std::vector<int> &ob = p.owner_is_q ? p.q_begin : p.p_begin, &gb = p.owner_is_q ? p.p_begin : p.q_begin;
             for (int x = 0; x < p.ns; ++x)
-                if ((unsigned long long)(gb[x + 1] - gb[x]) * p.ka * 4ull >= 0xFFFFFF00ull) {
-                    rc = fail(MFX_E_UNSUPPORTED, "a gathered stripe of 4 GB or more: use more stripes (mfx_options.stripes)");
+                if ((unsigned long long)(gb[x + 1] - gb[x]) * p.ka * 4ull >= 0xFFFFFF00ull ||
+                    (unsigned long long)(ob[x + 1] - ob[x]) * p.ka * 4ull >= 0xFFFFFF00ull) {
+                    rc = fail(MFX_E_UNSUPPORTED, "a stripe of 4 GB or more: use more stripes (mfx_options.stripes)");
                     return rc;
                 }
             HIP_TRY(t->dOwnBegin.alloc(ob.size()));
@@ -421,6 +432,19 @@ static int create_impl(const mfx::Node *R, const void *R_dev, long long nnz, int
     }
     std::vector<mfx::Entry>().swap(p.entries);
     std::vector<mfx::TaskDesc>().swap(p.tasks);
+    std::vector<mfx::WgTask>().swap(p.wg_tasks);
+    std::vector<mfx::WgVisitRec>().swap(p.wg_visits);
+    {
+        // L2 warm-up: only when every block's two stripes (rows + accumulators) fit the XCD's L2 with room to spare
+        const std::vector<int> &ob = p.owner_is_q ? p.q_begin : p.p_begin, &gb = p.owner_is_q ? p.p_begin : p.q_begin;
+        int max_own = 0, max_gat = 0;
+        for (int x = 0; x < p.ns; ++x) {
+            max_own = std::max(max_own, ob[x + 1] - ob[x]);
+            max_gat = std::max(max_gat, gb[x + 1] - gb[x]);
+        }
+        const size_t warm_bytes = ((size_t)max_own + max_gat) * ((size_t)p.ka * 4 + 8);
+        t->warm = warm_bytes <= (size_t)knob_int("MFX_WARM_KB", 3072) * 1024 ? 1 : 0;
+    }
     since("plan tables on the device");
     *out = t;
     return MFX_OK;
@@ -519,15 +543,14 @@ int mfx_trainer_init_model_counts(mfx_trainer *t, const int *omega_p, const int 
         }
         if (omega_p) HIP_TRY(hipMemcpy(t->dOmegaP.p, op.data(), (size_t)p.m * 4, hipMemcpyHostToDevice));
         if (omega_q) HIP_TRY(hipMemcpy(t->dOmegaQ.p, oq.data(), (size_t)p.n * 4, hipMemcpyHostToDevice));
-        if (env_int("MFX_HOST_INIT", 0) == 0) {
+        if (g_host_init == 0) {
             // the reference's single minstd_rand0 stream, entered per row by skip-ahead (prep.hip)
             mfx::init_factors_device(t->dOmegaP.p, p.m, t->dOmegaQ.p, p.n, p.p_at.empty() ? nullptr : p.p_at.data(),
                                      p.q_at.empty() ? nullptr : p.q_at.data(), p.k, p.ka, t->cu_count, t->stream,
                                      t->dP, t->dQ);
         } else {
             std::vector<float> P, Q;
-            mfx::init_factors(p, omega_p ? op.data() : nullptr, omega_q ? oq.data() : nullptr, P, Q,
-                              env_int("MFX_HOST_THREADS", 0));
+            mfx::init_factors(p, omega_p ? op.data() : nullptr, omega_q ? oq.data() : nullptr, P, Q, g_host_threads);
             HIP_TRY(hipMemcpy(t->dP, P.data(), P.size() * 4, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(t->dQ, Q.data(), Q.size() * 4, hipMemcpyHostToDevice));
         }
@@ -573,8 +596,8 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
     if (part == 0) {
         // one launch checks the cursors of the epoch before (sticky flag, read by verify_rounds) and zeroes
         // the loss sums and the task cursors
-        HIP_TRY(mfx::launch_epoch_reset(t->dLossP, t->dSlotStateP, t->dSlotPtr.p, ns * ns, t->cursors_live ? 1 : 0,
-                                        t->dSticky.p, s));
+        HIP_TRY(mfx::launch_epoch_reset(t->dLossP, t->dSlotStateP, t->dSlotPtr.p, t->dSlotWgPtr.p, ns * ns,
+                                        t->cursors_live ? 1 : 0, t->dSticky.p, s));
     }
 
     mfx::RoundArgs a;
@@ -585,6 +608,8 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
     a.hot_acc = t->dHotAcc.p;
     a.entries = t->dEntries.p;
     a.tasks = t->dTasks.p;
+    a.wg_tasks = t->dWgTasks.p;
+    a.wg_visits = t->dWgVisits.p;
     a.loss = t->dLossP;
     a.own_begin = t->dOwnBegin.p;
     a.gat_begin = t->dGatBegin.p;
@@ -655,28 +680,20 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
         if (!e0 || !e1) return fail(MFX_E_HIP, "hipEventCreate failed");
         HIP_TRY(hipEventRecord(e0, s));
     }
-    // L2 warm-up: only when every block's two stripes (rows + accumulators) fit the XCD's L2 with room to spare
-    const std::vector<int> &own_begin = p.owner_is_q ? p.q_begin : p.p_begin, &gat_begin = p.owner_is_q ? p.p_begin : p.q_begin;
-    int max_own = 0, max_gat = 0;
-    for (int x = 0; x < ns; ++x) {
-        max_own = std::max(max_own, own_begin[x + 1] - own_begin[x]);
-        max_gat = std::max(max_gat, gat_begin[x + 1] - gat_begin[x]);
-    }
-    const size_t warm_bytes = ((size_t)max_own + max_gat) * ((size_t)p.ka * 4 + 8);
-    a.warm = warm_bytes <= (size_t)env_int("MFX_WARM_KB", 3072) * 1024 ? 1 : 0;
+    a.warm = t->warm;
     a.waves_per_xcd = t->wgs_per_xcd * t->waves_per_wg;
     for (int i = i_begin; i < i_end; ++i) {
         const int r = (int)((i + t->epochs_done) % ns); // rotate the starting round per epoch
         a.round = r;
         a.slot_task_ptr = t->dSlotPtr.p + (size_t)r * ns;
         a.slot_cursor = t->dSlotStateP + (size_t)r * ns;
+        a.slot_wg_ptr = t->dSlotWgPtr.p + (size_t)r * ns;
+        a.wg_cursor = t->dSlotStateP + (size_t)ns * ns + (size_t)r * ns;
         HIP_TRY(mfx::launch_sgd_round(p.lanes, a, grid, s));
-        // the chains of the hot owner rows of this round are folded into their rows (kernels.hip: fold_hot_rows)
-        if (!p.round_hot.empty() && !p.round_hot[(size_t)r]) continue; // no chain in this round: nothing to fold
-        HIP_TRY(mfx::launch_fold_hot(a.own_rows, a.own_acc, t->dHotAcc.p, t->dHotRow.p, (int)p.n_hot_slots, p.ka, a.eta,
-                                     a.rk1, a.slow_only, env_int("MFX_FOLD_MODE", 0),
-                                     env_flt("MFX_HOT_S_GAIN", mfx::HOT_S_GAIN),
-                                     env_flt("MFX_HOT_S_N0", mfx::HOT_S_N0), env_flt("MFX_HOT_S_POW", mfx::HOT_S_POW), s));
+        // the copies of the rows of this round that are split over several workgroups are folded into their rows
+        if (p.round_hot.empty() || !p.round_hot[(size_t)r]) continue; // no such row in this round: nothing to fold
+        HIP_TRY(mfx::launch_fold_hot(a.own_rows, a.own_acc, a.gat_rows, a.gat_acc, t->dHotAcc.p, t->dHotRow.p, (int)p.n_hot_slots,
+                                     p.ka, a.eta, a.rk1, a.slow_only, s));
     }
     if (e1) {
         HIP_TRY(hipEventRecord(e1, s));
@@ -708,10 +725,12 @@ static int verify_rounds(mfx_trainer *t)
     if (sticky) return fail(MFX_E_STATE, msg);
     if (!t->loss_pending) return MFX_OK;
     const mfx::Plan &p = t->plan;
-    std::vector<int> cur((size_t)p.ns * p.ns);
+    const size_t nb = (size_t)p.ns * p.ns;
+    std::vector<int> cur(2 * nb);
     HIP_TRY(hipMemcpy(cur.data(), t->dSlotStateP, cur.size() * sizeof(int), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < cur.size(); ++i)
-        if (cur[i] < p.slot_task_ptr[i + 1] - p.slot_task_ptr[i]) return fail(MFX_E_STATE, msg);
+    for (size_t i = 0; i < nb; ++i)
+        if (cur[i] < p.slot_task_ptr[i + 1] - p.slot_task_ptr[i] || cur[nb + i] < p.slot_wg_ptr[i + 1] - p.slot_wg_ptr[i])
+            return fail(MFX_E_STATE, msg);
     t->loss_pending = false;
     return MFX_OK;
 }
@@ -808,6 +827,12 @@ int mfx_trainer_info(mfx_trainer *t, mfx_info *o)
     o->n_entries = t->n_entries;
     o->n_tasks = t->n_tasks;
     o->n_hot_rows = p.n_hot_rows;
+    o->n_wg_tasks = t->n_wg_tasks;
+    o->n_wg_visits = t->n_wg_visits;
+    o->n_hot_slots = p.n_hot_slots;
+    o->hot_acc_bytes = (long long)t->dHotAcc.n * 4;
+    o->waves_per_wg = t->waves_per_wg;
+    o->hot_len = p.hot_len;
     o->cu_count = t->cu_count;
     o->xcd_count = t->xcd_count;
     o->wg_per_cu = t->wg_per_cu;
@@ -900,6 +925,18 @@ int mfx_trainer_plan_copy(mfx_trainer *t, void *entries, void *tasks, long long 
     return MFX_OK;
 }
 
+int mfx_trainer_plan_copy_wg(mfx_trainer *t, void *wg_tasks, void *wg_visits, long long *slot_wg_ptr)
+{
+    if (!t) return fail(MFX_E_ARG, "null trainer");
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const mfx::Plan &p = t->plan;
+    if (wg_tasks && t->n_wg_tasks) HIP_TRY(hipMemcpy(wg_tasks, t->dWgTasks.p, (size_t)t->n_wg_tasks * sizeof(mfx::WgTaskD), hipMemcpyDeviceToHost));
+    if (wg_visits && t->n_wg_visits) HIP_TRY(hipMemcpy(wg_visits, t->dWgVisits.p, (size_t)t->n_wg_visits * sizeof(mfx::WgVisitD), hipMemcpyDeviceToHost));
+    if (slot_wg_ptr) memcpy(slot_wg_ptr, p.slot_wg_ptr.data(), p.slot_wg_ptr.size() * sizeof(long long));
+    return MFX_OK;
+}
+
 int mfx_trainer_timing_enable(mfx_trainer *t, int on)
 {
     if (!t) return fail(MFX_E_ARG, "null trainer");
@@ -969,21 +1006,23 @@ static int parse_header(const float *a, long long len, int &m, int &n, int &k, f
     return MFX_OK;
 }
 
-// ---- the model array of utility_predict, kept on the device ----------------------------------------------
-// The reference rebuilds the model from the float array on every call (array_to_model, mf/mf.cpp:3444-3481) and
-// so did round 1 here: one H2D copy of the whole array per call (384 MB for configs[2]).  A PHP request loop
-// calls utility_predict again and again with the SAME array, so the last array stays resident, keyed by host
-// pointer, length, header and a checksum over 16 K evenly spaced words -- hashing every word would cost more
-// than the copy it saves.  An array changed in place between two calls at none of the sampled words would be
-// missed: callers that do that call mfx_predict_cache_drop() (or set MFX_PREDICT_CACHE=0).
+// ---- the model array of utility_predict, optionally kept on the device -------------------------------------
+// The reference rebuilds the model from the float array on every call (array_to_model, mf/mf.cpp:3444-3481), and by
+// default so does this library: one H2D copy of the whole array per call (384 MB for configs[2], 15 ms of PCIe).  A PHP
+// request loop calls utility_predict again and again with the SAME array; a caller that wants the array to stay
+// resident between calls opts in -- mfx_predict_cache_enable(1), or MFX_PREDICT_CACHE=1 in the environment -- and
+// thereby promises to call mfx_predict_cache_drop() after changing an array in place.  The reuse is keyed by host
+// pointer, length, header and a checksum over 16 K evenly spaced words: a safety net, not a proof -- hashing every
+// word would cost more than the copy it saves, which is why the reuse is not the default.
 namespace {
 struct ModelCache {
     std::mutex mu;
+    bool enabled = g_predict_cache != 0;
     const float *host = nullptr;
     long long len = 0;
     unsigned long long sum = 0;
     float header[5] = {0, 0, 0, 0, 0};
-    int device = -1;
+    int device = -1;          // device that `dev` and `stream` belong to
     float *dev = nullptr;
     hipStream_t stream = nullptr;
     long long uploads = 0, hits = 0;
@@ -1003,31 +1042,41 @@ unsigned long long sample_sum(const float *a, long long len)
     return (h ^ w) * 1099511628211ull;
 }
 
-// device copy of the model array on the current device (cached); *stream = the cache's stream
+// device copy of the model array on the current device; *stream = the stream the copy was made on
 int resident_model(const float *model_arr, long long model_len, float **d_model, hipStream_t *stream)
 {
     ModelCache &c = g_model_cache;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
+    if (c.device != dev) { // buffer and stream belong to one device: start over on another
+        if (c.dev) {
+            if (c.device >= 0) (void)hipSetDevice(c.device);
+            (void)hipFree(c.dev);
+            if (c.stream) (void)hipStreamDestroy(c.stream);
+            (void)hipSetDevice(dev);
+        }
+        c.dev = nullptr;
+        c.stream = nullptr;
+        c.host = nullptr;
+        c.device = dev;
+    }
     if (!c.stream) HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    const bool use = env_int("MFX_PREDICT_CACHE", 1) != 0;
-    const unsigned long long sum = sample_sum(model_arr, model_len);
-    if (use && c.dev && c.host == model_arr && c.len == model_len && c.device == dev && c.sum == sum &&
+    const unsigned long long sum = c.enabled ? sample_sum(model_arr, model_len) : 0ull;
+    if (c.enabled && c.dev && c.host == model_arr && c.len == model_len && c.sum == sum &&
         memcmp(c.header, model_arr, sizeof(c.header)) == 0) {
         c.hits++;
     } else {
-        if (c.dev && (c.len != model_len || c.device != dev)) {
+        if (c.dev && c.len != model_len) {
             (void)hipFree(c.dev);
             c.dev = nullptr;
         }
         if (!c.dev) HIP_TRY(hipMalloc((void **)&c.dev, (size_t)model_len * 4));
         c.host = nullptr; // not valid until the copy is through
+        c.len = model_len;
         HIP_TRY(hipMemcpyAsync(c.dev, model_arr, (size_t)model_len * 4, hipMemcpyHostToDevice, c.stream));
         HIP_TRY(hipStreamSynchronize(c.stream));
         c.host = model_arr;
-        c.len = model_len;
         c.sum = sum;
-        c.device = dev;
         memcpy(c.header, model_arr, sizeof(c.header));
         c.uploads++;
     }
@@ -1037,12 +1086,17 @@ int resident_model(const float *model_arr, long long model_len, float **d_model,
 }
 } // namespace
 
+void mfx_predict_cache_enable(int on)
+{
+    std::lock_guard<std::mutex> lock(g_model_cache.mu);
+    g_model_cache.enabled = on != 0;
+    g_model_cache.host = nullptr;
+}
+
 void mfx_predict_cache_drop(void)
 {
     std::lock_guard<std::mutex> lock(g_model_cache.mu);
-    if (g_model_cache.dev) (void)hipFree(g_model_cache.dev);
-    g_model_cache.dev = nullptr;
-    g_model_cache.host = nullptr;
+    g_model_cache.host = nullptr; // the next call uploads again (the buffer itself is reused)
 }
 
 void mfx_predict_cache_stats(long long *uploads, long long *hits)
@@ -1189,6 +1243,14 @@ int mfx_hostplan_view(const mfx_hostplan *h, mfx_plan_view *v)
     v->p_begin = p.p_begin.data();
     v->q_begin = p.q_begin.data();
     v->n_hot_slots = p.n_hot_slots;
+    v->wg_tasks = p.wg_tasks.data();
+    v->wg_visits = p.wg_visits.data();
+    v->slot_wg_ptr = p.slot_wg_ptr.data();
+    v->n_wg_tasks = (long long)p.wg_tasks.size();
+    v->n_wg_visits = (long long)p.wg_visits.size();
+    v->waves_per_wg = p.waves_per_wg;
+    v->hot_len = p.hot_len;
+    v->hot_rows = p.hot_rows.data();
     return MFX_OK;
 }
 
@@ -1197,7 +1259,7 @@ int mfx_hostplan_init_factors(const mfx_hostplan *h, float *P, float *Q)
     if (!h || !P || !Q) return fail(MFX_E_ARG, "null pointer");
     try {
         std::vector<float> vp, vq;
-        mfx::init_factors(h->plan, nullptr, nullptr, vp, vq, env_int("MFX_HOST_THREADS", 0));
+        mfx::init_factors(h->plan, nullptr, nullptr, vp, vq, g_host_threads);
         memcpy(P, vp.data(), vp.size() * sizeof(float));
         memcpy(Q, vq.data(), vq.size() * sizeof(float));
         return MFX_OK;

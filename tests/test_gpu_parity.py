@@ -4,11 +4,11 @@ Tolerances (floating point; the path is lock-free and its update order differs f
 reference's, which is itself order-dependent -- SURVEY.md 3.4 Q2/Q3, 8d):
   * one conflict-free pass of the kernel vs orc_sgd_one, same inputs:   1e-5 relative
   * training, same triples / epochs / hyper-parameters: final training RMSE (calc_rmse formula) within
-    RMSE_RTOL = 3 % of the one-worker oracle's.  ONE number, used by every training test here, by
-    tests/test_gpu_multi.py, bench.py and README/DESIGN.md.  Where it comes from: the oracle
-    itself moves by +-1 % with nr_bins / block order alone; the sequential meaning of the GPU plan's order
-    (oracle/plan_order.c) sits within +-0.7 % of the reference's; folding the chains of the heavy rows adds
-    -2.2 .. +1.2 % (private row copies are not a sequential pass), the lock-free execution -0.2 .. -1.7 %.
+    RMSE_RTOL = 2 % of the one-worker oracle's, EVERY SINGLE RUN.  ONE number, used by every training test here, by
+    tests/test_gpu_multi.py, tests/test_gpu_heldout.py, bench.py and README/DESIGN.md.  Where it comes from:
+    the oracle itself moves by +-1 % with nr_bins / block order alone; the sequential meaning of the GPU plan's order
+    (oracle/plan_order.c) sits within -0.2 .. +1.4 % of the reference's; the heavy rows (one LDS copy per workgroup, a
+    handful of copies folded for the very heaviest) add -0.5 .. +1.1 %; the rest is the lock-free execution.
   * GPU vs the oracle's arithmetic walked in the GPU plan's own order (plan_order.c): 2 %
   * predictions / calc_rmse from the same model array:                   1e-5 relative
 """
@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-RMSE_RTOL = 0.03
+RMSE_RTOL = 0.02
 FULL = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size.json")))
 
 
@@ -199,11 +199,9 @@ def test_full_size_properties(pkg):
 
 @pytest.mark.parametrize("name,epochs", [("c1", 20), ("c2s", 12)])
 def test_other_epoch_counts_and_the_bench_sample(pkg, name, epochs):
-    """The facade's default is 20 iterations (reference mf/mf.cpp:4546): configs[1] after 20 epochs, where a damping of the hot
-    rows that is tuned at 12 epochs shows (it read +4.1 % before the lists stopped running their heavy rows first); and the
-    20 M-rating sample of configs[2] that bench.py times the CPU reference on.  The lock-free path is not deterministic: at
-    20 epochs single runs of configs[1] spread +-0.8 % (30 runs: +0.9 .. +2.5 %, median +1.7 %;
-    profiles/experiments/r02_fold_gain_shape.log), so the MEDIAN of five runs is held to the tolerance."""
+    """The facade's default is 20 iterations (reference mf/mf.cpp:4546): configs[1] after 20 epochs; and the 20 M-rating sample of
+    configs[2] that bench.py times the CPU reference on.  The lock-free path is not deterministic: THREE runs, EACH held to the
+    tolerance (round 2 held the median of five to 3 %)."""
     import torch
     g = FULL[name]
     m, n, nnz, k = g["m"], g["n"], g["nnz"], g["k"]
@@ -212,15 +210,14 @@ def test_other_epoch_counts_and_the_bench_sample(pkg, name, epochs):
     torch.cuda.synchronize()
     got = []
     t = pkg.Trainer(None, m, n, opts=pkg.default_options(k=k), device_ptr=R.data_ptr(), nnz=nnz)
-    for _ in range(5):
+    for _ in range(3):
         t.init_model()
         t.train(epochs)
         got.append(t.rmse())
     t.close()
     want = g["rmse_after"][str(epochs)]
-    rm = float(np.median(got))
-    assert abs(rm - want) / want < RMSE_RTOL, (got, want)
-    assert max(got) - min(got) < 0.025 * want, got  # run-to-run spread stays small (30 runs of configs[1]: 1.7 % from end to end)
+    print(name, epochs, "runs (rel. to the oracle, %):", [round((x / want - 1) * 100, 2) for x in got])
+    assert all(abs(x - want) / want < RMSE_RTOL for x in got), (got, want)
 
 
 def test_slow_only_epoch_touches_first_eight_factors(pkg):
@@ -251,9 +248,6 @@ def test_stripe_rotation_one_rank_is_plain_sgd(pkg, orc, world):
     import os
     import torch
     multi = _load_multi()
-    # isolate the rotation from the hot-row chain length (which follows the launch size and costs
-    # 2-3 % RMSE when short, DESIGN.md "Hot rows"): same chain bound as the single-trainer plan
-    os.environ["MFX_HOT_LEN"] = "128"
     m, n, nnz, k, iters = 60000, 30000, 6000000, 32, 8
     R = pkg.synth_host(3, 0, nnz, m, n)
     t = multi.RotatingTrainer(pkg, R, m, n, world, 0, None, torch.device("cuda", 0), k=k)
@@ -265,7 +259,6 @@ def test_stripe_rotation_one_rank_is_plain_sgd(pkg, orc, world):
     side.synchronize()
     got = t.rmse()
     t.close()
-    os.environ.pop("MFX_HOT_LEN")
     want = orc.rmse(R, orc.train(R, m, n, k=k, iters=iters))
     # Sweeping the item slots one after the other is a different (block-cyclic) order of the same updates.
     assert abs(got - want) / want < RMSE_RTOL, (got, want)
@@ -357,7 +350,9 @@ def test_gpu_follows_the_plan_order_emulation(pkg, orc):
     want_arr, want_tr = orc.plan_order_train(hp, iters, chain_mode=orc.CHAIN_FOLD)
     t = pkg.Trainer(R, m, n, k=k); t.init_model()
     e, ts, sp = t.plan_copy()
+    w, vv, wp = t.plan_copy_wg()
     assert np.array_equal(e, hp.entries) and np.array_equal(ts, hp.tasks)  # the emulation walks the very same plan
+    assert np.array_equal(w, hp.wg_tasks) and np.array_equal(vv, hp.wg_visits) and np.array_equal(wp, hp.slot_wg_ptr)
     tr = []
     for it in range(iters):
         t.epoch(slow_only=(it == 0)); tr.append(np.sqrt(t.last_loss() / nnz) * t.info.scale)
@@ -367,41 +362,76 @@ def test_gpu_follows_the_plan_order_emulation(pkg, orc):
     np.testing.assert_allclose(tr, want_tr, rtol=0.02)
 
 
-@pytest.mark.parametrize("k", [8, 40, 64])
-def test_hot_chain_fold_equals_the_emulation(pkg, orc, k):
-    """Eight items rated by 750 users each, every user exactly once: every visit is cut into chains, no gathered row is
-    touched twice, so nothing depends on timing -- the kernel's chains + fold_hot_rows must reproduce the plan-order
-    emulation's fold (same formula on the CPU) up to the order of the float sums."""
-    m, n = 6000, 8
+def _heavy_problem(pkg, m, k):
+    """Eight items rated by m/8 users each, every user exactly once: every item is a heavy row of every block (nothing
+    but workgroup tasks), and no row of the other side is touched twice."""
     rng = np.random.default_rng(k)
-    R = pkg.as_nodes(rng.permutation(m), np.arange(m) % n, rng.uniform(1, 5, m).astype(np.float32))
-    hp = pkg.HostPlan(R, m, n, k=k)
+    return pkg.as_nodes(rng.permutation(m), np.arange(m) % 8, rng.uniform(1, 5, m).astype(np.float32))
+
+
+@pytest.mark.parametrize("k", [8, 40, 64])
+def test_workgroup_visit_equals_the_emulation(pkg, orc, k):
+    """One wave per workgroup, one workgroup per XCD, forced workgroup tasks: nothing is concurrent, so the kernel's
+    workgroup path (the heavy row in LDS, LDS float atomics, the other side read-modified-written through buffer
+    descriptors) must reproduce the plan-order emulation -- the oracle's update on one LDS-like copy -- to float noise."""
+    m, n = 8000, 8
+    R = _heavy_problem(pkg, m, k)
+    kw = dict(k=k, wg_per_cu=0, task_steps=16)  # an explicit task size keeps the workgroup tasks on a one-workgroup launch
+    hp = pkg.HostPlan(R, m, n, **kw)
     v = hp.view
-    assert v.owner_is_q == 1 and v.n_hot_slots == n and (hp.entries["gat"] < -1).sum() >= 2 * n
-    t = pkg.Trainer(R, m, n, k=k); t.init_model()
-    e, ts, sp = t.plan_copy()
-    assert np.array_equal(e, hp.entries)
+    assert v.n_wg_tasks > 0 and len(hp.tasks) == 0 and (hp.wg_visits["info"] >> 1).max() == 1
+    exact = v.waves_per_wg == 1  # (wide rows run two waves per workgroup here: their adds interleave, second order in the step)
+    t = pkg.Trainer(R, m, n, **kw); t.init_model()
+    e, ts, sp = t.plan_copy(); w, vv, wp = t.plan_copy_wg()
+    assert np.array_equal(e, hp.entries) and np.array_equal(w, hp.wg_tasks) and np.array_equal(vv, hp.wg_visits)
     Pe, Qe = hp.init_factors()
     PGe, QGe = np.ones((m, 2), dtype=np.float32), np.ones((n, 2), dtype=np.float32)
-    ent, tsk, spp = (np.ascontiguousarray(x) for x in (hp.entries, hp.tasks, hp.slot_task_ptr))
-    sc = np.float32(v.scale)
-    loss = np.zeros(2)
-    orc.lib().orc_plan_order_train(ent.ctypes.data, tsk.ctypes.data, spp.ctypes.data, v.stripes, v.ratings_per_wave, v.k_aligned,
-                                   v.owner_is_q, Pe.ctypes.data, Qe.ctypes.data, PGe.ctypes.data, QGe.ctypes.data, v.n_hot_slots,
-                                   np.float32(0.1) / sc, np.float32(0.1) / sc, 0.1, 2, 0, orc.CHAIN_FOLD, orc.RSQRT_EXACT,
-                                   orc.RK_AS_BUILT, loss.ctypes.data)
-    t.epoch(slow_only=True); l0 = t.last_loss(); t.epoch(); l1 = t.last_loss(); t.sync()
+    loss = orc.plan_order_run(hp, Pe, Qe, PGe, QGe, 3)
+    got = []
+    for it in range(3):
+        t.epoch(slow_only=(it == 0)); got.append(t.last_loss())
     P, Q, PG, QG = t.get_model(); t.close()
-    np.testing.assert_allclose([l0, l1], loss, rtol=1e-4)
-    for got, want in ((Q, Qe), (QG, QGe), (P, Pe), (PG, PGe)):
-        np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(got, loss, rtol=1e-5 if exact else 5e-3)
+    for a_, b_ in ((Q, Qe), (QG, QGe), (P, Pe), (PG, PGe)):
+        np.testing.assert_allclose(a_, b_, rtol=2e-4 if exact else 3e-2, atol=2e-5 if exact else 3e-3)
+
+
+@pytest.mark.parametrize("k", [8, 40, 64])
+def test_split_rows_are_folded(pkg, orc, k):
+    """The same eight items with 10 000 users each on a full-width launch: a block IS one row, so the row is split over
+    every workgroup of the XCD -- visits of two steps, five to twenty copies folded behind every round.  That is the
+    most timing-sensitive shape there is (the emulation itself moves the second epoch's online error by 20 % when the
+    lists of a workgroup take turns instead of running side by side), so only what does not depend on timing is held
+    tightly: the plan, the first (eight-factor) epoch, the accumulators' growth, a falling error."""
+    m, n = 80000, 8
+    R = _heavy_problem(pkg, m, k)
+    hp = pkg.HostPlan(R, m, n, k=k)
+    v = hp.view
+    assert v.owner_is_q == 1 and v.n_hot_slots == n and v.n_wg_tasks > 0 and len(hp.tasks) == 0  # nothing but heavy rows
+    assert (hp.wg_visits["info"] >> 1).min() >= 2
+    t = pkg.Trainer(R, m, n, k=k); t.init_model()
+    e, ts, sp = t.plan_copy(); w, vv, wp = t.plan_copy_wg()
+    assert np.array_equal(e, hp.entries) and np.array_equal(w, hp.wg_tasks) and np.array_equal(vv, hp.wg_visits)
+    Pe, Qe = hp.init_factors()
+    PGe, QGe = np.ones((m, 2), dtype=np.float32), np.ones((n, 2), dtype=np.float32)
+    loss = orc.plan_order_run(hp, Pe, Qe, PGe, QGe, 1)
+    t.epoch(slow_only=True); l0 = t.last_loss()
+    P, Q, PG, QG = t.get_model()
+    assert abs(l0 - loss[0]) < 0.02 * loss[0]
+    np.testing.assert_allclose(QG, QGe, rtol=0.10)            # no accumulator growth lost, none counted twice
+    assert np.abs(Q - Qe).max() < 0.05 and np.array_equal(Q[:, 8:], Qe[:, 8:])
+    losses = [l0]
+    for it in range(3):
+        t.epoch(); losses.append(t.last_loss())
+    t.sync(); t.close()
+    assert np.isfinite(losses).all() and (np.diff(losses) < 0).all()
 
 
 def test_head_rows_keep_their_updates(pkg, orc):
-    """Data with a 5 % head user and a 7 % head item (what the synthetic generator of the bench produces).  A heavy
-    owner row is cut into chains that run side by side; round 1 let the last chain overwrite the others, so such a
-    row kept a fraction of its updates and of its Adagrad growth.  Now: the head rows' accumulators match what the
-    plan-order emulation (no lost update by construction) accumulates, and their per-row error stays near the oracle's."""
+    """Data with a 5 % head user and a 7 % head item (what the synthetic generator of the bench produces).  The head item is a
+    heavy owner row: worked by whole workgroups on LDS copies, no update and no Adagrad growth lost (round 1 let the last of
+    hundreds of chains overwrite the others: ~1/60 of the growth survived).  Its accumulators match what the plan-order
+    emulation accumulates, and both head rows' own error sits near the oracle's."""
     m, n, nnz, k, iters = 20000, 10000, 2000000, 32, 12
     R = pkg.synth_host(1, 0, nnz, m, n)
     cu, cv = np.bincount(R["u"], minlength=m), np.bincount(R["v"], minlength=n)
@@ -411,7 +441,7 @@ def test_head_rows_keep_their_updates(pkg, orc):
     t = pkg.Trainer(R, m, n, k=k); t.init_model(); t.train(iters)
     arr = t.export(); P, Q, PG, QG = t.get_model(); pm, qm = t.maps(); info = t.info; t.close()
     hp = pkg.HostPlan(R, m, n, k=k)
-    assert info.owner_is_q == 1 and hp.view.n_hot_slots > 0  # items are the owner side: the head item is cut into chains
+    assert info.owner_is_q == 1 and hp.view.n_wg_tasks > 0  # items are the owner side: the head item runs in workgroup tasks
 
     def row_rmse(a, side, row):
         Pm, Qm = a[5:5 + m * k].reshape(m, k), a[5 + m * k:].reshape(n, k)
@@ -420,20 +450,13 @@ def test_head_rows_keep_their_updates(pkg, orc):
 
     for side, row in (("u", hu), ("v", hv)):
         got, ref = row_rmse(arr, side, row), row_rmse(want, side, row)
-        assert abs(got - ref) / ref < 0.10, (side, got, ref)  # observed -5 .. +2 % (a row's own error is a noisy figure)
+        assert abs(got - ref) / ref < 0.05, (side, got, ref)  # (a single row's own error is a noisy figure)
     # accumulator growth of the head item: the emulation loses nothing by construction
-    import ctypes as C
     Pe, Qe = hp.init_factors()
     PGe, QGe = np.ones((m, 2), dtype=np.float32), np.ones((n, 2), dtype=np.float32)
-    v = hp.view
-    ent, tsk, sp = (np.ascontiguousarray(x) for x in (hp.entries, hp.tasks, hp.slot_task_ptr))
-    sc = np.float32(v.scale)
-    orc.lib().orc_plan_order_train(ent.ctypes.data, tsk.ctypes.data, sp.ctypes.data, v.stripes, v.ratings_per_wave, v.k_aligned,
-                                   v.owner_is_q, Pe.ctypes.data, Qe.ctypes.data, PGe.ctypes.data, QGe.ctypes.data, v.n_hot_slots,
-                                   np.float32(0.1) / sc, np.float32(0.1) / sc, 0.1, iters, 0, orc.CHAIN_FOLD, orc.RSQRT_EXACT,
-                                   orc.RK_AS_BUILT, None)
+    orc.plan_order_run(hp, Pe, Qe, PGe, QGe, iters)
     ghv = QG[qm[hv]]; ehv = QGe[hp.q_map[hv]]
-    assert np.all(ghv > 0.5 * ehv) and np.all(ghv < 2.0 * ehv), (ghv, ehv)  # last-writer-wins kept ~1/60 of it
+    assert np.all(np.abs(ghv - ehv) < 0.05 * ehv), (ghv, ehv)
 
 
 def test_triplets_to_device_matches_read_triplet(pkg):

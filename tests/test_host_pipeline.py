@@ -43,23 +43,38 @@ def check_plan(pkg, orc, R, m, n, k, **kw):
     hp = pkg.HostPlan(R, m, n, k=k, **kw)
     v = hp.view
     e, tasks, sptr = hp.entries, hp.tasks, hp.slot_task_ptr
-    NS, G = v.stripes, v.ratings_per_wave
-    assert G * v.lanes_per_rating == 64 and v.lanes_per_rating * 4 >= v.k_aligned
+    wgt, wgv, wptr = hp.wg_tasks, hp.wg_visits, hp.slot_wg_ptr
+    NS, G, W = v.stripes, v.ratings_per_wave, v.waves_per_wg
+    assert G * v.lanes_per_rating == 64 and v.lanes_per_rating * 4 >= v.k_aligned and 1 <= W <= 4
     act = e["gat"] >= 0
-    hdr = e["gat"] < -1  # header entries of hot chains: {row | bit 31, -(1 + chains of the row in this launch), slot}
-    assert act.sum() == len(R) and v.n_padding == len(e) - len(R) - hdr.sum()
-    # every rating exactly once, relabelled and scaled exactly as shuffle/scale_problem do
+    assert (e["gat"] >= -1).all()  # ratings and padding, nothing else
+    assert act.sum() == len(R) and v.n_padding == len(e) - len(R)
+    # every rating exactly once, relabelled and scaled exactly as shuffle/scale_problem do.  In a workgroup task of a
+    # heavy GATHERED row (bit 30 of `own`) the two ids have changed places.
     Ri = internal(R, hp, orc)
-    own = (e["own"][act] & 0x7FFFFFFF).astype(np.int64)
-    gat = e["gat"][act].astype(np.int64)
-    u, vv = (gat, own) if v.owner_is_q else (own, gat)
-    got = np.stack([u, vv, e["r"][act].view(np.uint32).astype(np.int64)], 1)
+    swp = ((e["own"] & pkg.ENTRY_SWAPPED) != 0)
+    a_id = (e["own"] & pkg.ENTRY_ID_MASK).astype(np.int64)
+    b_id = e["gat"].astype(np.int64)
+    own_id, gat_id = np.where(swp, b_id, a_id), np.where(swp, a_id, b_id)  # ids on the plan's owner / gathered side
+    u, vv = (gat_id, own_id) if v.owner_is_q else (own_id, gat_id)
+    got = np.stack([u[act], vv[act], e["r"][act].view(np.uint32).astype(np.int64)], 1)
     want = np.stack([Ri["u"].astype(np.int64), Ri["v"].astype(np.int64), Ri["r"].view(np.uint32).astype(np.int64)], 1)
     assert np.array_equal(got[np.lexsort(got.T[::-1])], want[np.lexsort(want.T[::-1])])
-    # tasks tile the entry array; step-major, G entries per step
+    # which ratings run with the roles swapped: the gathered row is heavy by its global count (more than hot_len ratings
+    # per block on average) and heavier than the rating's owner row -- and no others
+    om_o, om_g = (hp.omega_q, hp.omega_p) if v.owner_is_q else (hp.omega_p, hp.omega_q)
+    rule = (om_g[gat_id[act]] > v.hot_len * NS) & (om_g[gat_id[act]] > om_o[own_id[act]])
+    if kw.get("swap_heavy"):
+        assert np.array_equal(rule, swp[act])
+    else:
+        assert not swp.any()
+    # wave tasks and workgroup tasks together tile the entry array; step-major, G entries per step and wave
     assert sptr[0] == 0 and sptr[-1] == len(tasks) and (np.diff(sptr) >= 0).all()
-    assert int((tasks["nsteps"].astype(np.int64) * G).sum()) == len(e)
-    assert np.array_equal(tasks["off"][1:], np.cumsum(tasks["nsteps"].astype(np.int64) * G)[:-1].astype(np.uint64))
+    assert wptr[0] == 0 and wptr[-1] == len(wgt) and (np.diff(wptr) >= 0).all()
+    spans = [(int(t["off"]), int(t["nsteps"]) * G) for t in tasks] + [(int(t["off"]), int(t["nsteps"]) * G * W) for t in wgt]
+    spans.sort()
+    assert spans[0][0] == 0 and all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+    assert spans[-1][0] + spans[-1][1] == len(e)
     own_begin, gat_begin = (hp.q_begin, hp.p_begin) if v.owner_is_q else (hp.p_begin, hp.q_begin)
     for b, size in ((hp.p_begin, m), (hp.q_begin, n)):  # the stripes tile the id range
         assert b[0] == 0 and b[-1] == size and (np.diff(b) >= 0).all()
@@ -67,52 +82,74 @@ def check_plan(pkg, orc, R, m, n, k, **kw):
         assert np.array_equal(np.sort(mp), np.arange(size))
     stripe_o = lambda ids: np.searchsorted(own_begin, ids, side="right") - 1
     stripe_g = lambda ids: np.searchsorted(gat_begin, ids, side="right") - 1
-    own_all = (e["own"] & 0x7FFFFFFF).astype(np.int64)
+    slot_of = {}
     for r in range(NS):
         used_o, used_g = set(), set()
         for s in range(NS):
-            t0, t1 = sptr[r * NS + s], sptr[r * NS + s + 1]
-            if t0 == t1:
+            i = r * NS + s
+            rng_ = [(int(tasks["off"][t]), int(tasks["nsteps"][t]) * G) for t in range(sptr[i], sptr[i + 1])]
+            rng_ += [(int(wgt["off"][t]), int(wgt["nsteps"][t]) * G * W) for t in range(wptr[i], wptr[i + 1])]
+            if not rng_:
                 continue
-            lo = int(tasks["off"][t0]); hi = int(tasks["off"][t1 - 1]) + int(tasks["nsteps"][t1 - 1]) * G
-            a = e["gat"][lo:hi] >= 0
-            so = set(np.unique(stripe_o(own_all[lo:hi][a]))); sg = set(np.unique(stripe_g(e["gat"][lo:hi][a])))
+            idx = np.concatenate([np.arange(lo, lo + ln) for lo, ln in rng_])
+            idx = idx[act[idx]]
+            so, sg = set(np.unique(stripe_o(own_id[idx]))), set(np.unique(stripe_g(gat_id[idx])))
             # a block lives in ONE owner stripe and ONE gathered stripe ...
-            assert so == {s} and sg == {(s + r) % NS}
+            assert so <= {s} and sg <= {(s + r) % NS}
             # ... and the blocks of a round share no stripe (reference mf.cpp:133-141)
             assert not (so & used_o) and not (sg & used_g)
             used_o |= so; used_g |= sg
-    # inside every lane-group list: an owner change always carries the reload flag, and a list starts with one
+            # workgroup tasks of the block: the visits tile the steps; a visit's ratings all belong to its row and role,
+            # dealt over the W x G lists in contiguous runs: every list is filled from its first step, list after list
+            copies = {}
+            for t in range(wptr[i], wptr[i + 1]):
+                T = wgt[t]
+                vis = wgv[int(T["visit0"]): int(T["visit0"]) + int(T["nvisits"])]
+                assert int(vis["nsteps"].sum()) == int(T["nsteps"]) and int(T["nvisits"]) > 0
+                blk = e[int(T["off"]): int(T["off"]) + int(T["nsteps"]) * G * W].reshape(W, int(T["nsteps"]), G)
+                s0 = 0
+                for V in vis:
+                    part = blk[:, s0: s0 + int(V["nsteps"]), :]
+                    pa = part["gat"] >= 0
+                    assert pa.sum() == int(V["len"]) and (int(V["info"]) & 1) == int(T["swapped"])
+                    assert ((part["own"][pa] & pkg.ENTRY_ID_MASK) == int(V["row"])).all()
+                    assert (((part["own"][pa] & pkg.ENTRY_SWAPPED) != 0) == bool(T["swapped"])).all()
+                    assert not (part["own"][pa] >> 31).any()
+                    ns_v = int(V["nsteps"])
+                    assert ns_v == -(-int(V["len"]) // (W * G))
+                    per_list = pa.transpose(0, 2, 1).reshape(W * G, ns_v)     # list (wave, group) x step
+                    cnt = per_list.sum(1)
+                    assert all(per_list[l, :cnt[l]].all() for l in range(W * G))   # a list is filled from its first step ...
+                    full = int(V["len"]) // ns_v
+                    assert (cnt[:full] == ns_v).all() and (cnt[full + 1:] == 0).all()  # ... and the lists one after the other
+                    other = part["gat"].transpose(0, 2, 1).reshape(W * G, ns_v)
+                    flat = np.concatenate([other[l, :cnt[l]] for l in range(W * G)])
+                    assert (np.diff(flat) >= 0).all()                            # in the order of the other side's id
+                    key = (int(V["row"]), int(T["swapped"]))
+                    copies.setdefault(key, []).append(V)
+                    s0 += int(V["nsteps"])
+            for (row, side), vs in copies.items():
+                assert all(int(x["info"]) >> 1 == len(vs) for x in vs)  # every copy knows how many there are
+                if len(vs) > 1:  # a split row: ONE combine slot, the same in every block, that names the row and its side
+                    sl = {int(x["slot"]) for x in vs}
+                    assert len(sl) == 1 and slot_of.setdefault((row, side), sl) == sl
+                    assert int(hp.hot_rows[next(iter(sl))]) == (row | (side << 31))
+            # a heavy owner row is in workgroup tasks only: what is left in the wave tasks has at most hot_len ratings
+            widx = np.concatenate([np.arange(lo, lo + ln) for lo, ln in rng_[: sptr[i + 1] - sptr[i]]]) if sptr[i + 1] > sptr[i] else np.zeros(0, np.int64)
+            widx = widx[act[widx]] if len(widx) else widx
+            if len(widx):
+                assert np.bincount(a_id[widx]).max() <= v.hot_len and not swp[widx].any()
+    assert len({tuple(s) for s in slot_of.values()}) == len(slot_of) == v.n_hot_slots  # distinct rows, distinct slots
+    # inside every lane-group list of a wave task: an owner change always carries the reload flag, and a list starts with one
     for ti in range(len(tasks)):
         off, ns = int(tasks["off"][ti]), int(tasks["nsteps"][ti])
         blk = e[off: off + ns * G].reshape(ns, G)
         for g in range(G):
             col = blk[:, g]; a = col["gat"] >= 0; pad = col["gat"] == -1
-            ids = (col["own"][a] & 0x7FFFFFFF); fl = (col["own"][a] >> 31).astype(bool)
+            ids = (col["own"][a] & pkg.ENTRY_ID_MASK); fl = (col["own"][a] >> 31).astype(bool)
             if len(ids):
                 assert fl[0] and (fl[1:] | (ids[1:] == ids[:-1])).all()
                 assert not (~pad)[np.argmax(pad):].any() if pad.any() else True  # padding only at the tail
-            # a header is followed by the first rating of its chain: same row, reload flag set
-            for i in np.nonzero(col["gat"] < -1)[0]:
-                assert col["own"][i] >> 31 and i + 1 < ns and col["gat"][i + 1] >= 0
-                assert col["own"][i + 1] == col["own"][i]
-    # hot chains: within one launch (round) a row's headers all carry the same chain count, and there are exactly
-    # that many of them -- the kernel's last-chain test counts on it; a row keeps ONE combine slot everywhere
-    slot_of = {}
-    for r in range(NS):
-        t0, t1 = sptr[r * NS], sptr[(r + 1) * NS]
-        if t0 == t1:
-            continue
-        lo = int(tasks["off"][t0]); hi = int(tasks["off"][t1 - 1]) + int(tasks["nsteps"][t1 - 1]) * G
-        h = e[lo:hi][e["gat"][lo:hi] < -1]
-        rows, cnt = np.unique(h["own"] & 0x7FFFFFFF, return_counts=True)
-        for row, c in zip(rows, cnt):
-            mine = h[(h["own"] & 0x7FFFFFFF) == row]
-            code = -mine["gat"].astype(np.int64) - 1  # chains | index << 15
-            assert ((code & 0x7FFF) == c).all() and c >= 2 and sorted(code >> 15) == list(range(c))
-            slot = set((mine["r"].view(np.uint32) & 0xFFFFF).tolist())
-            assert len(slot) == 1 and slot_of.setdefault(int(row), slot) == slot
-    assert len({tuple(s) for s in slot_of.values()}) == len(slot_of)  # distinct rows, distinct slots
     return hp
 
 
@@ -121,6 +158,14 @@ def test_plan_layout_invariants(pkg, orc):
     check_plan(pkg, orc, R, 2500, 1800, 32)
     check_plan(pkg, orc, R, 2500, 1800, 8, stripes=4, task_steps=16)
     check_plan(pkg, orc, R, 2500, 1800, 64, owner_side=1)
+    check_plan(pkg, orc, R, 2500, 1800, 32, swap_heavy=1)
+    # heavy rows on both sides (the bench generator's 5 % head user and item), wide and narrow rows
+    R2 = pkg.synth_host(1, 0, 400000, 9000, 5000)
+    for k in (8, 32, 128):
+        hp = check_plan(pkg, orc, R2, 9000, 5000, k, task_steps=32)  # (an explicit task size: workgroup tasks even on a small launch)
+        assert hp.view.n_wg_tasks > 0 and (hp.wg_tasks["swapped"] == 0).all()
+        hp = check_plan(pkg, orc, R2, 9000, 5000, k, swap_heavy=1, task_steps=32)
+        assert (hp.wg_tasks["swapped"] == 1).any() and (hp.wg_tasks["swapped"] == 0).any()
 
 
 def test_stripes_are_mass_balanced(pkg, orc):
@@ -159,6 +204,8 @@ def test_plan_edge_cases(pkg, orc):
     hot["u"] = rng.integers(0, 900, 20000); hot["v"] = np.where(rng.random(20000) < 0.6, 7, rng.integers(0, 300, 20000))
     hot["r"] = rng.integers(1, 6, 20000)
     hp = check_plan(pkg, orc, hot, 900, 300, 16)
+    assert hp.view.n_hot_rows == 0 and hp.tasks["nsteps"].max() > 1000  # a one-workgroup launch: the heavy row is one long list
+    hp = check_plan(pkg, orc, hot, 900, 300, 16, task_steps=16)
     assert hp.view.n_hot_rows > 0
     # ragged: ids present only at the top of the range -> unseen rows, NaN init
     sparse = np.array([(999, 499, 1.0), (0, 0, 5.0), (999, 0, 2.0)], dtype=pkg.NODE)
@@ -191,19 +238,15 @@ def test_no_gpu_means_error_not_fallback(pkg):
         pkg.predict_array(arr, [0, 0])
 
 
-def test_monster_row_gets_longer_chains(pkg, monkeypatch):
-    """A row with more ratings in a block than 2^15 chains of the usual length hold (configs[4]'s head item on one GPU:
-    4.5 M ratings per block): the header entry counts chains in 15 bits, so such a row gets longer chains instead of an error."""
+def test_monster_row_is_split_over_workgroups(pkg, orc):
+    """A row that holds most of a block (configs[4]'s head item on one GPU: 4.5 M ratings per block) is more than one
+    workgroup does in a launch: it is split over several workgroups, every copy knows the count, one combine slot."""
     m, n, nnz = 20000, 16, 1200000
     rng = np.random.default_rng(0)
     v = np.zeros(nnz, dtype=np.int64); v[:100000] = rng.integers(1, n, 100000)
     R = pkg.as_nodes(rng.integers(0, m, nnz), v, rng.uniform(1, 5, nnz).astype(np.float32))
-    monkeypatch.setenv("MFX_HOT_LEN", "8")  # (the knob is read when the plan is built) 1.1 M / 8 blocks / 8 = 17 k ... per stripe
-    monkeypatch.setenv("MFX_STRIPES", "2")  # ... and two stripes make it 69 k chains of 8 for the head item's block
-    hp = pkg.HostPlan(R, m, n, k=8)
-    e = hp.entries
-    h = e[e["gat"] < -1]
-    code = -h["gat"].astype(np.int64) - 1
-    assert (e["gat"] >= 0).sum() == nnz
-    assert (code & 0x7FFF).max() <= 32767 and (code & 0x7FFF).max() > 20000   # capped, not failed
-    assert (h["r"].view(np.uint32) >> 20).max() > 8                           # ... by making the chains longer
+    hp = check_plan(pkg, orc, R, m, n, 8, stripes=2)
+    head = int(hp.q_map[0])
+    vis = hp.wg_visits[(hp.wg_visits["row"] == head) & ((hp.wg_visits["info"] & 1) == 0)]
+    assert len(vis) >= 4 and (vis["info"] >> 1).min() >= 2 and hp.view.n_hot_slots >= 1
+    assert int(vis["len"].sum()) == int((R["v"] == 0).sum())

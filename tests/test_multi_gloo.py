@@ -144,11 +144,11 @@ def test_slot_ring_three_ranks_overlapped():
     _check_ring(3, 2, epochs=2)
 
 
-def test_stripe_count_is_pinned_per_job(monkeypatch):
+def test_stripe_count_is_pinned_per_job():
     """The id layout depends on the stripe count (balanced_map deals heavy rows per stripe), so trainers that share
-    rows must not choose it from their own nnz.  mfx_stripes_for is what RotatingTrainer evaluates ONCE on the smallest piece
-    of the job and pins in every trainer.  (The size-dependent rule -- half the stripes for small pieces -- is off by
-    default since round 2, it cost parity; with it switched on, pieces 5 % apart in size choose different grids.)"""
+    rows must be given ONE count: mfx_stripes_for is what RotatingTrainer evaluates once for the job and pins in every
+    trainer.  It does not depend on a piece's size (round 1's "half the stripes for small pieces" cost parity and is gone),
+    and an explicit count always wins."""
     sys.path.insert(0, ROOT)
     import __graft_entry__ as ge
     pkg = ge.import_package()
@@ -156,16 +156,10 @@ def test_stripe_count_is_pinned_per_job(monkeypatch):
     m, n = 100000, 16667
     sizes = [int(x) for x in np.linspace(1.0e6, 6.0e6, 101)]
     assert {pkg.stripes_for(o, z, m, n) for z in sizes} == {8}
-    monkeypatch.setenv("MFX_HALF_STRIPES", "1")
-    st = [pkg.stripes_for(o, z, m, n) for z in sizes]
-    assert st[0] == 4 and st[-1] == 8
-    cut = st.index(8)
-    n_lo, n_hi = sizes[cut - 1], sizes[cut]
-    assert (pkg.stripes_for(o, n_lo, m, n), pkg.stripes_for(o, n_hi, m, n)) == (4, 8)
-    R = pkg.synth_host(1, 0, n_hi, m, n)
-    a = pkg.HostPlan(R[:n_lo], m, n, opts=pkg.default_options(k=32, stripes=4))
+    R = pkg.synth_host(1, 0, sizes[50], m, n)
+    a = pkg.HostPlan(R[: sizes[10]], m, n, opts=pkg.default_options(k=32, stripes=4))
     b = pkg.HostPlan(R, m, n, opts=pkg.default_options(k=32, stripes=4))
-    assert a.view.stripes == b.view.stripes == 4  # an explicit stripe count wins over the size heuristic
+    assert a.view.stripes == b.view.stripes == 4
     o.stripes = 8
     assert pkg.stripes_for(o, 1000, m, n) == 8
 

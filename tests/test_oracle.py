@@ -143,11 +143,7 @@ def test_plan_order_emulation_uses_the_pinned_update(pkg, orc, k):
     Pe, Qe, PGe, QGe = P.copy(), Q.copy(), PG.copy(), QG.copy()
     sc = np.float32(v.scale)
     lam = np.float32(0.1) / sc
-    ent, tsk, sp = (np.ascontiguousarray(x) for x in (hp.entries, hp.tasks, hp.slot_task_ptr))
-    loss = np.zeros(1)
-    orc.lib().orc_plan_order_train(ent.ctypes.data, tsk.ctypes.data, sp.ctypes.data, v.stripes, v.ratings_per_wave, v.k_aligned,
-                                   v.owner_is_q, Pe.ctypes.data, Qe.ctypes.data, PGe.ctypes.data, QGe.ctypes.data, v.n_hot_slots,
-                                   lam, lam, 0.1, 1, 1, orc.CHAIN_FOLD, orc.RSQRT_EXACT, orc.RK_AS_BUILT, loss.ctypes.data)
+    loss = orc.plan_order_run(hp, Pe, Qe, PGe, QGe, 1, first_epoch=1)
     Ri = R.copy()
     Ri["u"], Ri["v"] = hp.p_map[R["u"]], hp.q_map[R["v"]]
     Ri["r"] = (R["r"] * (np.float32(1.0) / sc)).astype(np.float32)
