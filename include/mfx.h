@@ -44,8 +44,8 @@ typedef struct mfx_options {
     int stripes;       /* stripe count per side = launches per epoch; 0 = one per XCD  */
     int wg_per_cu;     /* resident 256-thread workgroups per CU; 0 = auto              */
     int task_steps;    /* ratings per lane-group per task; 0 = auto                    */
-    int swap_heavy;    /* 1 (experimental): the heavy rows of the GATHERED side also run in workgroup tasks, with the
-                          roles swapped, instead of staying on the lock-free side (default 0; DESIGN.md "Heavy rows") */
+    int no_swap;       /* 1: leave the heavy rows of the GATHERED side on the lock-free side.  Default 0: their ratings run in
+                          workgroup tasks with the roles swapped (DESIGN.md "Heavy rows"; tests and A/B runs set it) */
     int rk_mode;       /* 0: 1/8 for both accumulator slots (SSE build as shipped,
                           mf.cpp:1233-1234); 1: 1/(k_a-8) for slot 1 (mf.cpp:1314-1315) */
     int owner_side;    /* 0 auto (side with fewer rows), 1 users (P), 2 items (Q)      */

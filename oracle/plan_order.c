@@ -35,11 +35,13 @@ typedef struct { uint64_t off; uint32_t nsteps; uint32_t visit0; uint32_t nvisit
 typedef struct { uint32_t row; uint32_t nsteps; uint32_t len; uint32_t info; uint32_t slot; uint32_t pad; } pl_wgvisit;
 
 #define IDMASK 0x3FFFFFFFu
+#define GAT_ID 0x3FFFFFFF  /* bit 30 of gat: the row is read, not written (plan.hpp ENTRY_READ_ONLY) */
+#define GAT_RO 0x40000000
 
 typedef struct {
     uint32_t cur; /* owner row of the visit in progress, 0xFFFFFFFF = none */
-    float og[2];
-    float *o;     /* private copy of the owner row (ka floats) */
+    float og[2], og0[2];
+    float *o;     /* private copy of the owner row (ka floats), followed by the state the visit started from */
 } pl_list;
 
 typedef struct {
@@ -64,21 +66,29 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
     float *own_rows = owner_is_q ? Q : P, *gat_rows = owner_is_q ? P : Q;
     float *own_acc = owner_is_q ? QG : PG, *gat_acc = owner_is_q ? PG : QG;
     const float lam_own = owner_is_q ? lambda_q : lambda_p, lam_gat = owner_is_q ? lambda_p : lambda_q;
+    float *const own_rows_ = own_rows, *const gat_rows_ = gat_rows, *const own_acc_ = own_acc, *const gat_acc_ = gat_acc;
+    const float lam_own_ = lam_own, lam_gat_ = lam_gat;
     const float rk1 = (rk_mode == ORC_RK_AS_BUILT || ka == 8) ? 0.125f : 1.0f / (float)(ka - 8);
     const size_t nslots = (size_t)(n_hot_slots > 0 ? n_hot_slots : 1);
     float *hot_acc = (float *)calloc(nslots * (size_t)(ka + 5), sizeof(float)); /* row, 2 acc, errors, ratings, copies */
     long long max_tasks = 0, max_wg = 0;
-    int i, ep;
+    int i, ep, merge_back = 0;
     pl_list *lists;
     pl_wg *wgs;
     float *copies, *wcopies, *snap = (float *)malloc(sizeof(float) * (size_t)(ka + 2)), *tmp = (float *)malloc(sizeof(float) * (size_t)(ka + 2));
     float *gsnap = (float *)malloc(sizeof(float) * (size_t)(ka + 2) * (size_t)G);
+    /* plans that run heavy rows of the GATHERED side with the roles swapped: those visits read-modify-write owner rows
+       while wave tasks hold them in registers, so the wave tasks (and one-copy workgroup visits) write back by merging */
+    for (i = 0; i < (int)slot_wg_ptr[ns * ns]; i++)
+        if (wgt[i].swapped) merge_back = 1;
+    for (i = 0; i < (int)slot_task_ptr[ns * ns]; i++)
+        if (tasks[i].pad) merge_back = 1;
     for (i = 0; i < ns * ns; i++) {
         if (slot_task_ptr[i + 1] - slot_task_ptr[i] > max_tasks) max_tasks = slot_task_ptr[i + 1] - slot_task_ptr[i];
         if (slot_wg_ptr[i + 1] - slot_wg_ptr[i] > max_wg) max_wg = slot_wg_ptr[i + 1] - slot_wg_ptr[i];
     }
     lists = (pl_list *)malloc((size_t)(max_tasks > 0 ? max_tasks : 1) * G * sizeof(pl_list));
-    copies = (float *)malloc((size_t)(max_tasks > 0 ? max_tasks : 1) * G * ka * sizeof(float));
+    copies = (float *)malloc((size_t)(max_tasks > 0 ? max_tasks : 1) * G * 2 * ka * sizeof(float));
     wgs = (pl_wg *)malloc((size_t)(max_wg > 0 ? max_wg : 1) * sizeof(pl_wg));
     wcopies = (float *)malloc((size_t)(max_wg > 0 ? max_wg : 1) * 2 * (size_t)(ka + 2) * sizeof(float));
 
@@ -97,7 +107,7 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
                 long long l, step, maxsteps = 0, t;
                 for (l = 0; l < nl; l++) {
                     lists[l].cur = 0xFFFFFFFFu;
-                    lists[l].o = copies + l * ka;
+                    lists[l].o = copies + l * 2 * ka;
                 }
                 for (t = wbeg; t < wend; t++) {
                     wgs[t - wbeg].visit = -1;
@@ -127,7 +137,11 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
                                 const unsigned ncop = V->info >> 1;
                                 float *rowp = o_rows + (size_t)V->row * ka, *accp = o_acc + (size_t)V->row * 2;
                                 const float *c = Wg->copy, *c0 = Wg->copy + ka + 2;
-                                if (ncop <= 1) { /* the one copy of the row is written back (like the owner row of a wave task) */
+                                if (ncop <= 1 && merge_back) {
+                                    for (d = 0; d < ka; d++) rowp[d] += c[d] - c0[d];
+                                    accp[0] += c[ka] - c0[ka];
+                                    accp[1] += c[ka + 1] - c0[ka + 1];
+                                } else if (ncop <= 1) { /* the one copy of the row is written back (like the owner row of a wave task) */
                                     memcpy(rowp, c, sizeof(float) * ka);
                                     accp[0] = c[ka];
                                     accp[1] = c[ka + 1];
@@ -160,42 +174,99 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
                         {
                             const pl_wgvisit *V = &wgv[T->visit0 + Wg->visit];
                             for (w = 0; w < W; w++) {
-                                const pl_entry *eb = entries + T->off + (uint64_t)w * T->nsteps * G + (uint64_t)step * G;
+                                const pl_entry *eb_raw = entries + T->off + (uint64_t)w * T->nsteps * G + (uint64_t)step * G;
+                                pl_entry eb[64];
+                                int ro[64];
+                                for (g = 0; g < G; g++) {
+                                    eb[g] = eb_raw[g];
+                                    ro[g] = eb[g].gat >= 0 && (eb[g].gat & GAT_RO) != 0;
+                                    if (eb[g].gat >= 0) eb[g].gat &= GAT_ID;
+                                }
                                 /* the wave reads the copy once per step; its G lists add what they change.  The rows of the
                                    other side are read by all G lists before any of them writes (one step of a wave = one
                                    burst of loads, then one burst of stores): of two lists that hold the same row in the
                                    same step, the later one's store wins */
                                 if (mode != 2) memcpy(snap, Wg->copy, sizeof(float) * (ka + 2));
-                                if (mode != 2 && mode != 4)
+                                {
+                                    /* all lists of the wave on the SAME row of the other side: their changes to it are summed
+                                       (row and accumulators), as the kernel does across the wave */
+                                    int nact_ = 0, same = 1, first = -1;
+                                    const int own_seq = mode == 4 || mode == 5, gat_seq = mode == 4 || mode == 6;
                                     for (g = 0; g < G; g++)
                                         if (eb[g].gat >= 0) {
-                                            memcpy(gsnap + (size_t)g * (ka + 2), g_rows + (size_t)eb[g].gat * ka, sizeof(float) * ka);
-                                            memcpy(gsnap + (size_t)g * (ka + 2) + ka, g_acc + (size_t)eb[g].gat * 2, sizeof(float) * 2);
+                                            if (first < 0) first = g;
+                                            else if (eb[g].gat != eb[first].gat) same = 0;
+                                            nact_++;
                                         }
-                                for (g = 0; g < G; g++) {
-                                    const pl_entry e = eb[g];
-                                    float err;
-                                    if (e.gat < 0) continue;
-                                    if (mode == 4) memcpy(snap, Wg->copy, sizeof(float) * (ka + 2));
-                                    if (mode == 2) {
-                                        err = orc_sgd_one(o_rows + (size_t)V->row * ka, g_rows + (size_t)e.gat * ka, o_acc + (size_t)V->row * 2,
-                                                          g_acc + (size_t)e.gat * 2, e.r, ka, lo, lg, eta, slow, rsqrt_mode, rk_mode);
-                                    } else {
-                                        float *gr = mode == 4 ? g_rows + (size_t)e.gat * ka : gsnap + (size_t)g * (ka + 2);
-                                        float *ga = mode == 4 ? g_acc + (size_t)e.gat * 2 : gr + ka;
-                                        memcpy(tmp, snap, sizeof(float) * (ka + 2));
-                                        err = orc_sgd_one(tmp, gr, tmp + ka, ga, e.r, ka, lo, lg, eta, slow, rsqrt_mode, rk_mode);
-                                        for (d = 0; d < ka + 2; d++) Wg->copy[d] += tmp[d] - snap[d];
+                                        same = same && nact_ > 1 && mode != 2 && !gat_seq;
+                                    if (mode != 2 && !gat_seq)
+                                        for (g = 0; g < G; g++)
+                                            if (eb[g].gat >= 0) {
+                                                memcpy(gsnap + (size_t)g * (ka + 2), g_rows + (size_t)eb[g].gat * ka, sizeof(float) * ka);
+                                                memcpy(gsnap + (size_t)g * (ka + 2) + ka, g_acc + (size_t)eb[g].gat * 2, sizeof(float) * 2);
+                                            }
+                                    /* The G lists of the wave step the heavy row from the same snapshot; their steps are summed.  Where the
+                                       lists pull the same way (the same pair repeated, or simply the common direction of all rows) the sum
+                                       overshoots what G ratings one after the other would do; with S = sum over the lists of step size x
+                                       curvature, a sequential pass contracts by exp(-S) where the sum contracts by S: the summed step is
+                                       scaled by (1 - exp(-S)) / S -- the fold's own 1-D model, one wave at a time (1 while S is small). */
+                                    float wdamp = 1.0f;
+                                    if (!own_seq && mode != 2) {
+                                        float S = 0.0f;
+                                        const float e0_ = eta / sqrtf(snap[ka]), e1_ = eta / sqrtf(snap[ka + 1]);
+                                        for (g = 0; g < G; g++)
+                                            if (eb[g].gat >= 0) {
+                                                const float *gr_ = g_rows + (size_t)eb[g].gat * ka;
+                                                for (d = 0; d < (slow ? 8 : ka); d++) S += (d < 8 ? e0_ : e1_) * gr_[d] * gr_[d];
+                                            }
+                                        wdamp = damp(S);
                                     }
-                                    Wg->tsum += err * err;
-                                    loss += (double)(err * err);
-                                }
-                                if (mode != 2 && mode != 4)
-                                    for (g = 0; g < G; g++)
-                                        if (eb[g].gat >= 0) {
-                                            memcpy(g_rows + (size_t)eb[g].gat * ka, gsnap + (size_t)g * (ka + 2), sizeof(float) * ka);
-                                            memcpy(g_acc + (size_t)eb[g].gat * 2, gsnap + (size_t)g * (ka + 2) + ka, sizeof(float) * 2);
+                                    for (g = 0; g < G; g++) {
+                                        const pl_entry e = eb[g];
+                                        float err;
+                                        if (e.gat < 0) continue;
+                                        if (own_seq) memcpy(snap, Wg->copy, sizeof(float) * (ka + 2));
+                                        if (ro[g] && (mode == 2 || gat_seq)) { /* read, not written: work on a scratch copy of that row */
+                                            memcpy(gsnap + (size_t)g * (ka + 2), g_rows + (size_t)e.gat * ka, sizeof(float) * ka);
+                                            memcpy(gsnap + (size_t)g * (ka + 2) + ka, g_acc + (size_t)e.gat * 2, sizeof(float) * 2);
                                         }
+                                        if (mode == 2) {
+                                            float *gr2 = ro[g] ? gsnap + (size_t)g * (ka + 2) : g_rows + (size_t)e.gat * ka;
+                                            float *ga2 = ro[g] ? gr2 + ka : g_acc + (size_t)e.gat * 2;
+                                            err = orc_sgd_one(o_rows + (size_t)V->row * ka, gr2, o_acc + (size_t)V->row * 2, ga2, e.r, ka, lo, lg, eta, slow,
+                                                              rsqrt_mode, rk_mode);
+                                        } else {
+                                            float *gr = gat_seq && !ro[g] ? g_rows + (size_t)e.gat * ka : gsnap + (size_t)g * (ka + 2);
+                                            float *ga = gat_seq && !ro[g] ? g_acc + (size_t)e.gat * 2 : gr + ka;
+                                            memcpy(tmp, snap, sizeof(float) * (ka + 2));
+                                            err = orc_sgd_one(tmp, gr, tmp + ka, ga, e.r, ka, lo, lg, eta, slow, rsqrt_mode, rk_mode);
+                                            for (d = 0; d < ka; d++) Wg->copy[d] += wdamp * (tmp[d] - snap[d]);
+                                            for (d = ka; d < ka + 2; d++) Wg->copy[d] += tmp[d] - snap[d];
+                                        }
+                                        Wg->tsum += err * err;
+                                        loss += (double)(err * err);
+                                    }
+                                    if (same && ro[first]) {
+                                        /* (read-only: nothing is written) */
+                                    } else if (same) {
+                                        float *rowm = g_rows + (size_t)eb[first].gat * ka, *accm = g_acc + (size_t)eb[first].gat * 2;
+                                        for (g = 0; g < G; g++)
+                                            if (eb[g].gat >= 0) { /* gsnap held the old value plus this list's change: add the change */
+                                                const float *gs = gsnap + (size_t)g * (ka + 2);
+                                                if (g == first) continue;
+                                                for (d = 0; d < ka; d++) gsnap[(size_t)first * (ka + 2) + d] += gs[d] - rowm[d];
+                                                gsnap[(size_t)first * (ka + 2) + ka] += gs[ka] - accm[0];
+                                                gsnap[(size_t)first * (ka + 2) + ka + 1] += gs[ka + 1] - accm[1];
+                                            }
+                                        memcpy(rowm, gsnap + (size_t)first * (ka + 2), sizeof(float) * ka);
+                                        memcpy(accm, gsnap + (size_t)first * (ka + 2) + ka, sizeof(float) * 2);
+                                    } else if (mode != 2 && !gat_seq)
+                                        for (g = 0; g < G; g++)
+                                            if (eb[g].gat >= 0 && !ro[g]) {
+                                                memcpy(g_rows + (size_t)eb[g].gat * ka, gsnap + (size_t)g * (ka + 2), sizeof(float) * ka);
+                                                memcpy(g_acc + (size_t)eb[g].gat * 2, gsnap + (size_t)g * (ka + 2) + ka, sizeof(float) * 2);
+                                            }
+                                }
                             }
                         }
                     }
@@ -204,8 +275,13 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
                         int g;
                         const long long step = tstep;
                         const int ended = step >= tasks[t].nsteps;
-                        int acts[64];
+                        int acts[64], ros[64];
                         pl_entry es[64];
+                        /* role 1 (tasks[t].pad): the lists are visits of rows of the plan's GATHERED side, roles swapped */
+                        const int tsw = (int)tasks[t].pad;
+                        float *own_rows = tsw ? gat_rows_ : own_rows_, *gat_rows = tsw ? own_rows_ : gat_rows_;
+                        float *own_acc = tsw ? gat_acc_ : own_acc_, *gat_acc = tsw ? own_acc_ : gat_acc_;
+                        const float lam_own = tsw ? lam_gat_ : lam_own_, lam_gat = tsw ? lam_own_ : lam_gat_;
                         if (step > tasks[t].nsteps) continue;
                         /* one step of a wave: visits are switched, then all G lists read their row of the other side, then all
                            write it (of two lists that hold the same row in the same step, the later one's store wins) */
@@ -228,12 +304,22 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
                                 newvisit = act && (e.own >> 31) && id != L->cur;
                             }
                             acts[g] = act;
+                            ros[g] = act && (e.gat & GAT_RO) != 0;
+                            if (act) e.gat &= GAT_ID;
                             es[g] = e;
                             if (newvisit) {
                                 if (L->cur != 0xFFFFFFFFu) { /* close_visit: the row is written back */
-                                    memcpy(own_rows + (size_t)L->cur * ka, L->o, sizeof(float) * ka);
-                                    own_acc[(size_t)L->cur * 2] = L->og[0];
-                                    own_acc[(size_t)L->cur * 2 + 1] = L->og[1];
+                                    float *rowp = own_rows + (size_t)L->cur * ka, *accp = own_acc + (size_t)L->cur * 2;
+                                    if (merge_back) { /* ... as what memory holds NOW plus what the visit changed */
+                                        int d;
+                                        for (d = 0; d < ka; d++) rowp[d] += L->o[d] - L->o[ka + d];
+                                        accp[0] += L->og[0] - L->og0[0];
+                                        accp[1] += L->og[1] - L->og0[1];
+                                    } else {
+                                        memcpy(rowp, L->o, sizeof(float) * ka);
+                                        accp[0] = L->og[0];
+                                        accp[1] = L->og[1];
+                                    }
                                 }
                                 if (ended) {
                                     L->cur = 0xFFFFFFFFu;
@@ -241,8 +327,9 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
                                 }
                                 L->cur = id;
                                 memcpy(L->o, own_rows + (size_t)id * ka, sizeof(float) * ka);
-                                L->og[0] = own_acc[(size_t)id * 2];
-                                L->og[1] = own_acc[(size_t)id * 2 + 1];
+                                memcpy(L->o + ka, L->o, sizeof(float) * ka);
+                                L->og[0] = L->og0[0] = own_acc[(size_t)id * 2];
+                                L->og[1] = L->og0[1] = own_acc[(size_t)id * 2 + 1];
                             }
                         }
                         if (ended) continue;
@@ -254,14 +341,15 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
                         for (g = 0; g < G; g++)
                             if (acts[g]) {
                                 pl_list *L = &lists[(t - tbeg) * G + g];
-                                float *gr = mode == 2 || mode == 4 ? gat_rows + (size_t)es[g].gat * ka : gsnap + (size_t)g * (ka + 2);
-                                float *ga = mode == 2 || mode == 4 ? gat_acc + (size_t)es[g].gat * 2 : gr + ka;
+                                const int inplace = (mode == 2 || mode == 4 || mode == 6) && !ros[g];
+                                float *gr = inplace ? gat_rows + (size_t)es[g].gat * ka : gsnap + (size_t)g * (ka + 2);
+                                float *ga = inplace ? gat_acc + (size_t)es[g].gat * 2 : gr + ka;
                                 const float err = orc_sgd_one(L->o, gr, L->og, ga, es[g].r, ka, lam_own, lam_gat, eta, slow, rsqrt_mode, rk_mode);
                                 loss += (double)(err * err);
                             }
-                        if (mode != 2 && mode != 4)
+                        if (mode != 2 && mode != 4 && mode != 6)
                             for (g = 0; g < G; g++)
-                                if (acts[g]) {
+                                if (acts[g] && !ros[g]) {
                                     memcpy(gat_rows + (size_t)es[g].gat * ka, gsnap + (size_t)g * (ka + 2), sizeof(float) * ka);
                                     memcpy(gat_acc + (size_t)es[g].gat * 2, gsnap + (size_t)g * (ka + 2) + ka, sizeof(float) * 2);
                                 }

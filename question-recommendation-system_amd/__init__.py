@@ -22,7 +22,7 @@ TASK = np.dtype([("off", "<u8"), ("nsteps", "<u4"), ("pad", "<u4")])
 # workgroup tasks (the heavy rows, include/mfx.h mfx_plan_view): entries stored wave-major, visits tile the steps
 WGTASK = np.dtype([("off", "<u8"), ("nsteps", "<u4"), ("visit0", "<u4"), ("nvisits", "<u4"), ("swapped", "<u4")])
 WGVISIT = np.dtype([("row", "<u4"), ("nsteps", "<u4"), ("len", "<u4"), ("info", "<u4"), ("slot", "<u4"), ("pad", "<u4")])
-ENTRY_SWAPPED, ENTRY_ID_MASK = 0x40000000, 0x3FFFFFFF
+ENTRY_SWAPPED, ENTRY_ID_MASK, ENTRY_READ_ONLY = 0x40000000, 0x3FFFFFFF, 0x40000000
 
 # Itanium names of the five symbols an unchanged libphp_mf.so imports
 MANGLED = {
@@ -41,7 +41,7 @@ class MfxError(RuntimeError):
 class Options(C.Structure):
     _fields_ = [("k", C.c_int), ("lambda_p2", C.c_float), ("lambda_q2", C.c_float),
                 ("eta", C.c_float), ("device", C.c_int), ("stripes", C.c_int),
-                ("wg_per_cu", C.c_int), ("task_steps", C.c_int), ("swap_heavy", C.c_int),
+                ("wg_per_cu", C.c_int), ("task_steps", C.c_int), ("no_swap", C.c_int),
                 ("rk_mode", C.c_int), ("owner_side", C.c_int), ("identity_maps", C.c_int),
                 ("use_stats", C.c_int), ("stats_avg", C.c_float), ("stats_std", C.c_float),
                 ("reserved", C.c_int * 1)]

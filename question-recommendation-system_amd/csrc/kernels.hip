@@ -63,6 +63,19 @@ __device__ __forceinline__ float group_sum(float x)
     return x;
 }
 
+// Sum over the lanes of a wavefront that hold the same factors of DIFFERENT ratings (same position inside their LANES-lane
+// group): rotations inside a 16-lane row (DPP row_ror), ds_bpermute across rows.  Every lane gets the total.
+template <int LANES>
+__device__ __forceinline__ float cross_group_sum(float x)
+{
+    if (LANES <= 2) x += dpp<0x122>(x);  // row_ror:2
+    if (LANES <= 4) x += dpp<0x124>(x);  // row_ror:4
+    if (LANES <= 8) x += dpp<0x128>(x);  // row_ror:8
+    if (LANES <= 16) x += __shfl_xor(x, 16);
+    if (LANES <= 32) x += __shfl_xor(x, 32);
+    return x;
+}
+
 // LDS float add without a return value (ds_add_f32)
 __device__ __forceinline__ void lds_add(float *p, float v)
 {
@@ -142,15 +155,17 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
     constexpr int G = 64 / LANES;
     constexpr int EBLK = 128; // entries per block of the entry stream (two per lane); EBLK/G steps
     static_assert(EBLK / G >= 4, "a block of the entry stream must span at least four steps");
-    constexpr unsigned NONE = 0xFFFFFFFFu, IDMASK = 0x7FFFFFFFu;
+    constexpr unsigned NONE = 0xFFFFFFFFu, IDMASK = 0x3FFFFFFFu; // (bit 31 of `own`: a visit starts; bit 30: roles swapped)
+    constexpr int GAT_ID = 0x3FFFFFFF, GAT_RO = 0x40000000; // bit 30 of `gat`: read the row, do not write it (plan.hpp ENTRY_READ_ONLY)
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     __shared__ u4 ering_all[4][2 * EBLK]; // per wave: a ring of two blocks, 16-byte slots
     u4 *const ering = ering_all[threadIdx.x >> 6];
     __shared__ int wg_first;
     // workgroup tasks: the heavy row of the visit in progress lives here (LDS float atomics from every list of the workgroup)
-    __shared__ f4 lrow4[64];
-    __shared__ float lacc[2];
-    __shared__ float lE;
+    __shared__ f4 lrow4_all[2][64]; // two buffers: the next visit's row is staged while the current one is worked on
+    __shared__ float lacc_all[2][2];
+    __shared__ float lE_all[2];
+    __shared__ float lg_init[2]; // the smaller accumulator slot as the visit found it (read by every wave: must not change under it)
 #ifdef MFX_OWNER_LDS
     // experiment (make variant VFLAGS=-DMFX_OWNER_LDS): the "LDS-staged latent tile" for the one side that has re-use -- the
     // owner row of a visit lives in LDS (read before and written after every update) instead of in registers
@@ -265,36 +280,53 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                         fetch_block(0, r0, r1);
                         park_block(0, r0, r1);
                         e = entry_of(0);
-                        grow = e.gat >= 0 && lane_ok ? (unsigned)(e.gat - wfirst) * (unsigned)(ka * 4) + d0 * 4 : BUF_OOB;
-                        gacc = e.gat >= 0 ? (unsigned)(e.gat - wfirst) * 8u : BUF_OOB;
+                        grow = e.gat >= 0 && lane_ok ? (unsigned)((e.gat & GAT_ID) - wfirst) * (unsigned)(ka * 4) + d0 * 4 : BUF_OOB;
+                        gacc = e.gat >= 0 ? (unsigned)((e.gat & GAT_ID) - wfirst) * 8u : BUF_OOB;
                         gn = bld_row(w_rows, grow);
                         ggn = bld_acc(w_acc, gacc);
                     }
                     float tsum = 0.0f;
                     int step = 0;
-                    for (int v = 0; v < nvisits; ++v) {
-                        const WgVisitD *const vp = a.wg_visits + visit0 + v;
-                        const unsigned row = (unsigned)__builtin_amdgcn_readfirstlane((int)vp->row);
-                        const int vsteps = __builtin_amdgcn_readfirstlane((int)vp->nsteps);
-                        const unsigned vlen = (unsigned)__builtin_amdgcn_readfirstlane((int)vp->len);
-                        const unsigned vinfo = (unsigned)__builtin_amdgcn_readfirstlane((int)vp->info);
-                        const unsigned vslot = (unsigned)__builtin_amdgcn_readfirstlane((int)vp->slot);
-                        __syncthreads(); // the visit before is through with the LDS row (its write-back included)
-                        f4 x0 = zero4;
-                        f2 g0 = {1.0f, 1.0f};
-                        if (wv == 0 && grp == 0) {
-                            if (lane_ok) {
-                                x0 = ld_row(o_rows + (size_t)row * ka + d0);
-                                lrow4[lig] = x0;
-                            }
-                            if (lig == 0) {
-                                g0 = ld_acc(o_acc + (size_t)row * 2);
-                                lacc[0] = g0.x;
-                                lacc[1] = g0.y;
-                                lE = 0.0f;
-                            }
+                    // Visit records and rows are fetched one visit ahead: a record read at the top of its visit would cost a
+                    // memory round trip before the first step, the row another one.
+                    auto visit_rec = [&](int v, unsigned &row, int &vsteps, unsigned &vlen, unsigned &vinfo, unsigned &vslot) {
+                        const WgVisitD *const vp = a.wg_visits + visit0 + (v < nvisits ? v : nvisits - 1);
+                        row = (unsigned)__builtin_amdgcn_readfirstlane((int)vp->row);
+                        vsteps = __builtin_amdgcn_readfirstlane((int)vp->nsteps);
+                        vlen = (unsigned)__builtin_amdgcn_readfirstlane((int)vp->len);
+                        vinfo = (unsigned)__builtin_amdgcn_readfirstlane((int)vp->info);
+                        vslot = (unsigned)__builtin_amdgcn_readfirstlane((int)vp->slot);
+                    };
+                    const bool stager = wv == 0 && grp == 0; // the lanes that move the heavy row between memory and LDS
+                    unsigned row, vlen, vinfo, vslot, row_n, vlen_n, vinfo_n, vslot_n;
+                    int vsteps, vsteps_n;
+                    visit_rec(0, row, vsteps, vlen, vinfo, vslot);
+                    f4 x0 = zero4, xn = zero4;   // the state the visit started from (what its change is measured against) / the next one's
+                    f2 g0 = {1.0f, 1.0f}, g0n = {1.0f, 1.0f};
+                    __syncthreads(); // (the task before is through with both buffers)
+                    if (stager) {
+                        if (lane_ok) {
+                            x0 = ld_row(o_rows + (size_t)row * ka + d0);
+                            lrow4_all[0][lig] = x0;
                         }
-                        __syncthreads();
+                        if (lig == 0) {
+                            g0 = ld_acc(o_acc + (size_t)row * 2);
+                            lacc_all[0][0] = g0.x;
+                            lacc_all[0][1] = g0.y;
+                            lE_all[0] = 0.0f;
+                            lg_init[0] = SLOW ? g0.x : fminf(g0.x, g0.y);
+                        }
+                    }
+                    __syncthreads();
+                    for (int v = 0; v < nvisits; ++v) {
+                        const int cur = v & 1;
+                        f4 *const lrow4 = lrow4_all[cur];
+                        float *const lacc = lacc_all[cur];
+                        visit_rec(v + 1, row_n, vsteps_n, vlen_n, vinfo_n, vslot_n);
+                        if (stager && v + 1 < nvisits) { // the next visit's row, in flight while this visit runs
+                            if (lane_ok) xn = ld_row(o_rows + (size_t)row_n * ka + d0);
+                            if (lig == 0) g0n = ld_acc(o_acc + (size_t)row_n * 2);
+                        }
                         const float tsum0 = tsum;
                         auto wg_step = [&]() {
                                 const EntryD enext = entry_of(step + 1);
@@ -321,76 +353,144 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                                 float so = 0.0f, sg = 0.0f;
                                 f2 d01 = {0.0f, 0.0f}, d23 = {0.0f, 0.0f};
                                 const bool move = upd && act;
+                                // The G lists of the wave step the heavy row from the same snapshot and their steps are summed.  Where
+                                // the lists pull the same way (one pair repeated over and over, or simply the direction all rows have
+                                // in common) the sum overshoots what G ratings one after the other would do: with S = sum over the
+                                // lists of step size x curvature, a sequential pass contracts by exp(-S) where the sum contracts by S.
+                                // The summed step is scaled by (1 - exp(-S)) / S -- the fold's 1-D model, one wave-step at a time; 1
+                                // to first order while S is small (it is, except in the first steps of a run and for large eta:
+                                // eta = 0.2 overflowed without it).
+                                float wdamp;
+                                {
+                                    const f2 q2 = g01 * g01 + g23 * g23;
+                                    const float S = cross_group_sum<LANES>(group_sum<LANES>(move ? eta_o * (q2.x + q2.y) : 0.0f));
+                                    wdamp = S > 1e-3f ? (1.0f - __expf(-S)) / S : 1.0f - 0.5f * S;
+                                }
                                 if (move) {
                                     const f2 go01 = wl_o * o01 - err * g01, go23 = wl_o * o23 - err * g23;
                                     const f2 gq01 = wl_g * g01 - err * o01, gq23 = wl_g * g23 - err * o23;
                                     const f2 so2 = go01 * go01 + go23 * go23, sg2 = gq01 * gq01 + gq23 * gq23;
                                     so = so2.x + so2.y;
                                     sg = sg2.x + sg2.y;
-                                    d01 = -eta_o * go01;
-                                    d23 = -eta_o * go23;
+                                    d01 = -(eta_o * wdamp) * go01;
+                                    d23 = -(eta_o * wdamp) * go23;
                                     g01 -= eta_g * gq01;
                                     g23 -= eta_g * gq23;
                                     g = f4{g01.x, g01.y, g23.x, g23.y};
                                 }
                                 const bool nact = enext.gat >= 0 && step + 1 < tsteps;
-                                grow = nact && lane_ok ? (unsigned)(enext.gat - wfirst) * (unsigned)(ka * 4) + d0 * 4 : BUF_OOB;
-                                gacc = nact ? (unsigned)(enext.gat - wfirst) * 8u : BUF_OOB;
-                                bst_row(w_rows, grow_c, g);
+                                grow = nact && lane_ok ? (unsigned)((enext.gat & GAT_ID) - wfirst) * (unsigned)(ka * 4) + d0 * 4 : BUF_OOB;
+                                gacc = nact ? (unsigned)((enext.gat & GAT_ID) - wfirst) * 8u : BUF_OOB;
+                                float sg0 = group_sum<LANES>(slot1 ? 0.0f : sg), sg1 = 0.0f;
+                                if (!SLOW) sg1 = group_sum<LANES>(slot1 ? sg : 0.0f);
+                                // All lists of the wave on the SAME row of the other side (the synthetic streams repeat a pair --
+                                // heavy user, heavy item -- thousands of times; sorted, those ratings fill list after list): every
+                                // list read the row before any of them wrote it, so the row would keep ONE of their steps and
+                                // one rating's accumulator growth -- steps that stay too large on a row that is hit that often
+                                // (eta = 0.2: the row oscillates until it overflows).  The lists' changes are summed across the
+                                // wave instead, row and accumulators, and every list stores the same result.
                                 {
-                                    const float sg0 = group_sum<LANES>(slot1 ? 0.0f : sg);
-                                    gg.x = gg.x + sg0 * rk0;
-                                    if (!SLOW) {
-                                        const float sg1 = group_sum<LANES>(slot1 ? sg : 0.0f);
-                                        gg.y = gg.y + sg1 * rk1;
+                                    const unsigned long long m_act = __ballot(act);
+                                    if (m_act != 0ull && G > 1) {
+                                        const int gid = __builtin_amdgcn_readlane(e.gat, (int)__builtin_ctzll(m_act));
+                                        const bool same = __ballot(act && e.gat != gid) == 0ull && __builtin_popcountll(m_act) > LANES;
+                                        if (same) {
+                                            const f4 gold = gn; // (what every list loaded)
+                                            g.x = gold.x + cross_group_sum<LANES>(act ? g.x - gold.x : 0.0f);
+                                            g.y = gold.y + cross_group_sum<LANES>(act ? g.y - gold.y : 0.0f);
+                                            g.z = gold.z + cross_group_sum<LANES>(act ? g.z - gold.z : 0.0f);
+                                            g.w = gold.w + cross_group_sum<LANES>(act ? g.w - gold.w : 0.0f);
+                                            sg0 = cross_group_sum<LANES>(sg0);
+                                            if (!SLOW) sg1 = cross_group_sum<LANES>(sg1);
+                                        }
                                     }
-                                    bst_acc(w_acc, gacc_c, gg);
                                 }
+                                const bool ro = (e.gat & GAT_RO) != 0; // the other row of a pair of two heavy rows: read, never written here
+                                bst_row(w_rows, ro ? BUF_OOB : grow_c, g);
+                                gg.x = gg.x + sg0 * rk0;
+                                if (!SLOW) gg.y = gg.y + sg1 * rk1;
+                                bst_acc(w_acc, ro ? BUF_OOB : gacc_c, gg);
                                 gn = bld_row(w_rows, grow);
                                 ggn = bld_acc(w_acc, gacc);
-                                // the heavy row's own update: LDS float atomics (ds_add_f32), so that no list's change is lost
-                                if (move) {
-                                    float *const lr = (float *)lrow4 + d0;
-                                    lds_add(lr + 0, d01.x);
-                                    lds_add(lr + 1, d01.y);
-                                    lds_add(lr + 2, d23.x);
-                                    lds_add(lr + 3, d23.y);
+                                // The heavy row's own update.  The G lists of this wave all hold the SAME row: what they change is
+                                // summed across the lane groups in registers first (DPP / ds_bpermute), and one group adds the
+                                // total with LDS float atomics (ds_add_f32) -- the other waves of the workgroup add theirs the
+                                // same way, so no list's change is lost.  (Every group adding for itself is G lanes on every
+                                // address: the LDS runs those one after the other, and a step took four times as long.)
+                                {
+                                    const float t0 = cross_group_sum<LANES>(d01.x), t1 = cross_group_sum<LANES>(d01.y);
+                                    const float t2 = cross_group_sum<LANES>(d23.x), t3 = cross_group_sum<LANES>(d23.y);
+                                    if (grp == 0 && upd) {
+                                        float *const lr = (float *)lrow4 + d0;
+                                        lds_add(lr + 0, t0);
+                                        lds_add(lr + 1, t1);
+                                        lds_add(lr + 2, t2);
+                                        lds_add(lr + 3, t3);
+                                    }
                                 }
-                                const float so0 = group_sum<LANES>(slot1 ? 0.0f : so);
-                                if (lig == 0 && act) lds_add(&lacc[0], so0 * rk0);
+                                const float so0 = cross_group_sum<LANES>(group_sum<LANES>(slot1 ? 0.0f : so));
+                                if (lane == 0) lds_add(&lacc[0], so0 * rk0);
                                 if (!SLOW) {
-                                    const float so1 = group_sum<LANES>(slot1 ? so : 0.0f);
-                                    if (lig == 0 && act) lds_add(&lacc[1], so1 * rk1);
+                                    const float so1 = cross_group_sum<LANES>(group_sum<LANES>(slot1 ? so : 0.0f));
+                                    if (lane == 0) lds_add(&lacc[1], so1 * rk1);
                                 }
                                 e = enext;
                         };
-                        // The FIRST step of a visit is taken by the waves in turn.  Side by side, W x G lists would all read
-                        // the row as the visit found it and add their steps to it at once; while the row's accumulators are
-                        // still small (epoch 0: G = 1, step size eta itself) that sum overshoots -- 128 simultaneous
-                        // ratings at k = 8 move the row 4 x beyond its optimum and the visit never recovers.  After one
-                        // step in turn the accumulators hold W x G ratings' growth and the steps are small enough to add.
-                        for (int s = 0; s < vsteps; ++s, ++step) {
-                            if (s == 0) {
-                                for (int tw = 0; tw < a.active_waves; ++tw) {
-                                    if (wv == tw) wg_step();
-                                    __syncthreads();
-                                }
-                            } else if (wave_on) {
-                                wg_step();
+                        // While the row's accumulators are still small (epoch 0: G = 1, step size eta itself) the FIRST step of a
+                        // visit is taken by the waves in turn.  Side by side, W x G lists would all read the row as the visit found
+                        // it and add their steps to it at once; that sum overshoots -- 128 simultaneous ratings at k = 8 move the
+                        // row 4 x beyond its optimum and the visit never recovers.  After one step in turn the accumulators hold
+                        // W x G ratings' growth and the steps are small enough to add.  The bound is where eta/sqrt(G) x (a row
+                        // norm of 4) x (W x G ratings) reaches 1; every heavy row is past it after an epoch or two.
+                        const float gmin = lg_init[cur];
+                        const float gneed = eta * 4.0f * (float)(a.active_waves * G);
+                        const bool in_turn = __builtin_amdgcn_readfirstlane((int)(gmin < gneed * gneed)) != 0;
+                        if (in_turn) {
+                            for (int tw = 0; tw < a.active_waves; ++tw) {
+                                if (wv == tw) wg_step();
+                                __syncthreads();
+                            }
+                            ++step;
+                        }
+                        if (wave_on)
+                            for (int s = in_turn ? 1 : 0; s < vsteps; ++s, ++step) wg_step();
+                        else
+                            step += vsteps - (in_turn ? 1 : 0);
+                        if (wave_on && lig == 0) lds_add(&lE_all[cur], tsum - tsum0);
+                        if (stager && v + 1 < nvisits) { // stage the next visit's row in the other buffer (its last user is long done)
+                            if (lane_ok) lrow4_all[cur ^ 1][lig] = xn;
+                            if (lig == 0) {
+                                lacc_all[cur ^ 1][0] = g0n.x;
+                                lacc_all[cur ^ 1][1] = g0n.y;
+                                lE_all[cur ^ 1] = 0.0f;
+                                lg_init[cur ^ 1] = SLOW ? g0n.x : fminf(g0n.x, g0n.y);
                             }
                         }
-                        if (wave_on && lig == 0) lds_add(&lE, tsum - tsum0);
-                        __syncthreads(); // every list's adds have landed
-                        if (wv == 0 && grp == 0) {
+                        __syncthreads(); // every list's adds have landed; the next visit's row is staged
+                        if (stager) {
                             // One workgroup held ALL of the row's ratings of this block: the copy is the row, written back like the
                             // owner row of a wave task.  A row split over several workgroups: every copy adds what it CHANGED
                             // (end state minus the state it started from -- sums of end states cancel catastrophically for a
                             // row of many copies), its squared errors, its ratings and 1 to the row's combine slot with
                             // fire-and-forget float atomics; fold_hot_rows, launched behind the round, folds the copies.
+                            // (The other waves are already in the next visit, on the other buffer.)
                             const unsigned ncop = vinfo >> 1;
-                            if (ncop <= 1) {
+                            if (ncop <= 1 && !a.merge_back) {
                                 if (lane_ok) *(f4 *)(o_rows + (size_t)row * ka + d0) = lrow4[lig];
                                 if (lig == 0) *(f2 *)(o_acc + (size_t)row * 2) = f2{lacc[0], lacc[1]};
+                            } else if (ncop <= 1) { // (roles swapped somewhere in the plan: other visits may have touched the row meanwhile)
+                                float *const dst = o_rows + (size_t)row * ka;
+                                if (lane_ok) {
+                                    const f4 x1 = lrow4[lig];
+                                    unsafeAtomicAdd(dst + d0 + 0, x1.x - x0.x);
+                                    unsafeAtomicAdd(dst + d0 + 1, x1.y - x0.y);
+                                    unsafeAtomicAdd(dst + d0 + 2, x1.z - x0.z);
+                                    unsafeAtomicAdd(dst + d0 + 3, x1.w - x0.w);
+                                }
+                                if (lig == 0) {
+                                    unsafeAtomicAdd(o_acc + (size_t)row * 2, lacc[0] - g0.x);
+                                    unsafeAtomicAdd(o_acc + (size_t)row * 2 + 1, lacc[1] - g0.y);
+                                }
                             } else {
                                 float *const dst = a.hot_acc + ((size_t)vslot * HOT_SUB + (size_t)(wt & (HOT_SUB - 1))) * (size_t)(ka + HOT_EXTRA);
                                 if (lane_ok) {
@@ -403,12 +503,19 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                                 if (lig == 0) {
                                     unsafeAtomicAdd(dst + ka, lacc[0] - g0.x);
                                     unsafeAtomicAdd(dst + ka + 1, lacc[1] - g0.y);
-                                    unsafeAtomicAdd(dst + ka + 2, lE);           // squared errors of this copy
+                                    unsafeAtomicAdd(dst + ka + 2, lE_all[cur]);  // squared errors of this copy
                                     unsafeAtomicAdd(dst + ka + 3, (float)vlen);  // its ratings
                                     unsafeAtomicAdd(dst + ka + 4, 1.0f);         // one more copy
                                 }
                             }
                         }
+                        x0 = xn;
+                        g0 = g0n;
+                        row = row_n;
+                        vsteps = vsteps_n;
+                        vlen = vlen_n;
+                        vinfo = vinfo_n;
+                        vslot = vslot_n;
                     }
                     if (wave_on && lig == 0) lsum += (double)tsum;
                 }
@@ -446,15 +553,24 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
             // the descriptor is the same for every lane: keep it in SGPRs, so that the step loop
             // below branches on scalars (real branches, no exec-masked loop exits)
             unsigned long long toff;
-            int nsteps;
+            int nsteps, trole; // (role 1: the lists of this task are visits of rows of the GATHERED side, roles swapped)
             EntryD nb0, nb1;
             {
                 const TaskDescD td = a.tasks[tbeg + c];
                 toff = uniform_off(td);
                 nsteps = __builtin_amdgcn_readfirstlane((int)td.nsteps);
+                trole = __builtin_amdgcn_readfirstlane((int)td.pad);
                 fetch_first(toff, nsteps, nb0, nb1);
             }
+            // the other role's descriptors: the owner stripe is the one that is read-modified-written
+            const __amdgpu_buffer_rsrc_t rs_rows_sw = make_rsrc(a.own_rows + (size_t)ofirst * ka, (unsigned)on_rows * (unsigned)(ka * 4));
+            const __amdgpu_buffer_rsrc_t rs_acc_sw = make_rsrc(a.own_acc + (size_t)ofirst * 2, (unsigned)on_rows * 8u);
             for (;;) {
+                const bool tsw = trole != 0;
+                float *const t_own_rows = tsw ? a.gat_rows : a.own_rows, *const t_own_acc = tsw ? a.gat_acc : a.own_acc;
+                const __amdgpu_buffer_rsrc_t t_rows = tsw ? rs_rows_sw : rs_rows, t_acc = tsw ? rs_acc_sw : rs_acc;
+                const int t_first = tsw ? ofirst : gfirst;
+                const float t_lam_o = tsw ? lam_g : lam_o, t_lam_g = tsw ? lam_o : lam_g;
                 int cn_v = 0, cn = ntask; // the next task: claim in flight / claimed index
                 // The claim goes out eight steps before the task ends: late enough that the waves of an
                 // XCD, which start their tasks together, do not all ask at once (atomics on one address
@@ -464,7 +580,7 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                 const int claim_at = nsteps > 12 ? nsteps - 8 : 0;
                 TaskDescD tdn_v = {0, 0, 0};
                 unsigned long long toff_n = 0;
-                int nsteps_n = 0;
+                int nsteps_n = 0, trole_n = 0;
 
                 unsigned cur = NONE;  // owner row held in registers
                 f4 o = zero4;
@@ -508,8 +624,8 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                 EntryD e = entry_of(0);
                 if (e.gat != -1) { // every list starts with a visit: fetch its owner row now
                     pf = e.own & IDMASK;
-                    if (lane_ok) on = ld_row(a.own_rows + (size_t)pf * ka + d0);
-                    ogn = ld_acc(a.own_acc + (size_t)pf * 2);
+                    if (lane_ok) on = ld_row(t_own_rows + (size_t)pf * ka + d0);
+                    ogn = ld_acc(t_own_acc + (size_t)pf * 2);
                 }
                 // Every memory operation of a step goes out in ONE burst at the end of its update
                 // window, in this order: row store, accumulator store, the NEXT step's gathered row
@@ -521,21 +637,31 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                 // The gathered side is addressed through buffer descriptors over the block's gathered
                 // stripe (32-bit offsets); pad entries and lanes past k_a use an offset beyond it --
                 // the range check loads zeros and drops the store -- so every access is unconditional.
-                unsigned grow = e.gat >= 0 && lane_ok ? (unsigned)(e.gat - gfirst) * (unsigned)(ka * 4) + d0 * 4 : BUF_OOB;
-                unsigned gacc = e.gat >= 0 ? (unsigned)(e.gat - gfirst) * 8u : BUF_OOB;
-                f4 gn = bld_row(rs_rows, grow);
-                f2 ggn = bld_acc(rs_acc, gacc);
+                unsigned grow = e.gat >= 0 && lane_ok ? (unsigned)((e.gat & GAT_ID) - t_first) * (unsigned)(ka * 4) + d0 * 4 : BUF_OOB;
+                unsigned gacc = e.gat >= 0 ? (unsigned)((e.gat & GAT_ID) - t_first) * 8u : BUF_OOB;
+                f4 gn = bld_row(t_rows, grow);
+                f2 ggn = bld_acc(t_acc, gacc);
                 STAMP(tk1);
 #ifdef MFX_STAMPS
                 c_task += tk1 - tk0;
                 n_tasks++;
 #endif
+                // Plans that run heavy rows of the gathered side with the roles swapped (mfx_options.swap_heavy): those visits
+                // read-modify-write owner rows while a wave task holds them in registers.  The visit then writes back what
+                // memory holds NOW (om, fetched one step before the visit ends) plus what it changed, instead of its copy.
+                f4 o_start = zero4, om = zero4;
+                f2 og_start = {1.0f, 1.0f}, ogm = {1.0f, 1.0f};
                 auto close_visit = [&]() {
 #ifdef MFX_OWNER_LDS
                     o = own_tile[threadIdx.x];
 #endif
-                    if (lane_ok) *(f4 *)(a.own_rows + (size_t)cur * ka + d0) = o;
-                    if (lig == 0) *(f2 *)(a.own_acc + (size_t)cur * 2) = f2{og0, og1};
+                    if (a.merge_back) {
+                        if (lane_ok) *(f4 *)(t_own_rows + (size_t)cur * ka + d0) = om + (o - o_start);
+                        if (lig == 0) *(f2 *)(t_own_acc + (size_t)cur * 2) = f2{ogm.x + (og0 - og_start.x), ogm.y + (og1 - og_start.y)};
+                        return;
+                    }
+                    if (lane_ok) *(f4 *)(t_own_rows + (size_t)cur * ka + d0) = o;
+                    if (lig == 0) *(f2 *)(t_own_acc + (size_t)cur * 2) = f2{og0, og1};
                 };
                 for (int step = 0; step < nsteps; ++step) {
                     STAMP(ts0);
@@ -545,12 +671,13 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     const bool act = e.gat >= 0;
                     const unsigned id = e.own & IDMASK;
                     const float rating = e.r;
+                    const bool ro = (e.gat & GAT_RO) != 0; // (plan.hpp ENTRY_READ_ONLY)
                     const bool newvisit = act && (e.own >> 31) && id != cur;
                     if (newvisit) { // switch the owner row: write the old one back, take the prefetched one
                         if (cur != NONE) close_visit();
                         if (pf != id) { // not prefetched (cannot happen for lists built by plan.cpp)
-                            if (lane_ok) on = ld_row(a.own_rows + (size_t)id * ka + d0);
-                            ogn = ld_acc(a.own_acc + (size_t)id * 2);
+                            if (lane_ok) on = ld_row(t_own_rows + (size_t)id * ka + d0);
+                            ogn = ld_acc(t_own_acc + (size_t)id * 2);
                         }
                         o = on;
 #ifdef MFX_OWNER_LDS
@@ -558,6 +685,8 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
 #endif
                         og0 = ogn.x;
                         og1 = ogn.y;
+                        o_start = on;
+                        og_start = ogn;
                         cur = id;
                     }
                     f4 g = gn;
@@ -576,6 +705,7 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                         } else if (cn < ntask) {
                             toff_n = uniform_off(tdn_v);
                             nsteps_n = __builtin_amdgcn_readfirstlane((int)tdn_v.nsteps);
+                            trole_n = __builtin_amdgcn_readfirstlane((int)tdn_v.pad);
                             fetch_first(toff_n, nsteps_n, nb0, nb1);
                         }
                     }
@@ -604,8 +734,8 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     float so = 0.0f, sg = 0.0f;
                     if (upd && act) {
                         // both gradients use the OLD values of the other side
-                        const f2 go01 = lam_o * o01 - err * g01, go23 = lam_o * o23 - err * g23;
-                        const f2 gq01 = lam_g * g01 - err * o01, gq23 = lam_g * g23 - err * o23;
+                        const f2 go01 = t_lam_o * o01 - err * g01, go23 = t_lam_o * o23 - err * g23;
+                        const f2 gq01 = t_lam_g * g01 - err * o01, gq23 = t_lam_g * g23 - err * o23;
                         const f2 so2 = go01 * go01 + go23 * go23, sg2 = gq01 * gq01 + gq23 * gq23;
                         so = so2.x + so2.y;
                         sg = sg2.x + sg2.y;
@@ -621,19 +751,24 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     }
                     // ---- one burst of memory operations ----
                     const bool nact = enext.gat >= 0 && step + 1 < nsteps;
-                    grow = nact && lane_ok ? (unsigned)(enext.gat - gfirst) * (unsigned)(ka * 4) + d0 * 4 : BUF_OOB;
-                    gacc = nact ? (unsigned)(enext.gat - gfirst) * 8u : BUF_OOB;
+                    grow = nact && lane_ok ? (unsigned)((enext.gat & GAT_ID) - t_first) * (unsigned)(ka * 4) + d0 * 4 : BUF_OOB;
+                    gacc = nact ? (unsigned)((enext.gat & GAT_ID) - t_first) * 8u : BUF_OOB;
                     const unsigned id1 = enext.own & IDMASK;
                     auto owner_prefetch = [&]() {
-                        if (nact && (enext.own >> 31) && id1 != cur) { // a visit starts at the next step
+                        const bool switches = nact && (enext.own >> 31) && id1 != cur; // a visit starts at the next step
+                        if (switches) {
                             pf = id1;
-                            if (lane_ok) on = ld_row(a.own_rows + (size_t)id1 * ka + d0);
-                            ogn = ld_acc(a.own_acc + (size_t)id1 * 2);
+                            if (lane_ok) on = ld_row(t_own_rows + (size_t)id1 * ka + d0);
+                            ogn = ld_acc(t_own_acc + (size_t)id1 * 2);
+                        }
+                        if (a.merge_back && cur != NONE && (switches || step + 1 >= nsteps || !nact)) { // the visit in progress ends
+                            if (lane_ok) om = ld_row(t_own_rows + (size_t)cur * ka + d0);
+                            ogm = ld_acc(t_own_acc + (size_t)cur * 2);
                         }
                     };
                     auto next_loads = [&]() {
-                        gn = bld_row(rs_rows, grow);
-                        ggn = bld_acc(rs_acc, gacc);
+                        gn = bld_row(t_rows, grow);
+                        ggn = bld_acc(t_acc, gacc);
                     };
                     auto acc_store = [&]() {
                         const float sg0 = group_sum<LANES>(slot1 ? 0.0f : sg);
@@ -642,12 +777,12 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                             const float sg1 = group_sum<LANES>(slot1 ? sg : 0.0f);
                             gg.y = gg.y + sg1 * rk1;
                         }
-                        bst_acc(rs_acc, gacc_c, gg); // every lane of the group writes the same pair
+                        bst_acc(t_acc, ro ? BUF_OOB : gacc_c, gg); // every lane of the group writes the same pair
                     };
                     STAMP(tsb);
                     // the gathered row goes back first: the time between its load and this store is the
                     // window in which another wave's update of the same row is lost
-                    bst_row(rs_rows, grow_c, g);
+                    bst_row(t_rows, ro ? BUF_OOB : grow_c, g);
                     // accumulator store, then the next step's loads: the wait at the top of the next step
                     // covers the whole burst.  (Sending the loads ahead of the accumulator store, with the
                     // wait leaving that store in flight, paid for wide rows before the buffer addressing and
@@ -685,12 +820,14 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                 if (nsteps < claim_at + 3 && cn < ntask) {
                     toff_n = uniform_off(tdn_v);
                     nsteps_n = __builtin_amdgcn_readfirstlane((int)tdn_v.nsteps);
+                    trole_n = __builtin_amdgcn_readfirstlane((int)tdn_v.pad);
                     fetch_first(toff_n, nsteps_n, nb0, nb1);
                 }
                 if (cn >= ntask) break;
                 c = cn;
                 toff = toff_n;
                 nsteps = nsteps_n;
+                trole = trole_n;
             }
         }
 
@@ -863,7 +1000,7 @@ __global__ __launch_bounds__(256) void sq_err_entries(const float *own_rows, con
             if (act && lane_ok) {
                 const bool sw = (e.own & 0x40000000u) != 0; // a heavy row of the gathered side: `own` indexes that side
                 f4 o = *(const f4 *)((sw ? gat_rows : own_rows) + (size_t)(e.own & 0x3FFFFFFFu) * ka + d0);
-                f4 g = *(const f4 *)((sw ? own_rows : gat_rows) + (size_t)e.gat * ka + d0);
+                f4 g = *(const f4 *)((sw ? own_rows : gat_rows) + (size_t)(e.gat & 0x3FFFFFFF) * ka + d0);
                 z = o.x * g.x + o.y * g.y + o.z * g.z + o.w * g.w;
             }
             r = e.r;

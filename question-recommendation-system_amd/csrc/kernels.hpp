@@ -43,6 +43,7 @@ struct RoundArgs {
     // descriptors over that stripe (a stripe must stay below 4 GB) and can stream both stripes into L2.
     const int *own_begin, *gat_begin;
     int round;
+    int merge_back;                 // 1: the plan swaps roles for heavy gathered rows: owner rows are written back by merging
     int warm;                       // 1: stream the stripes of each slot into L2 before the first step
     int waves_per_xcd;              // waves that take work in one XCD (warm-up chunks are dealt over them)
     signed char xcc_rank[16];       // HW_REG_XCC_ID -> rank in [0, n_xcc), -1 = takes no work

@@ -186,7 +186,7 @@ long long block_steps_per_wave(const std::vector<Visit> &raw, int G, int W, int 
     const long long WGL = (long long)W * G;
     long long L_main = 0, hot_steps = 0;
     for (const Visit &v : raw) {
-        if (!v.swapped && (long long)v.len <= hot_len) L_main += v.len;
+        if ((long long)v.len <= hot_len) L_main += v.len;
         else hot_steps += ((long long)v.len + WGL - 1) / WGL;
     }
     if (hot_steps_out) *hot_steps_out = hot_steps;
@@ -213,13 +213,13 @@ static void pack_block(std::vector<Visit> &raw, int G, int W, int waves, int tar
     const long long WGL = (long long)W * G;
     long long hot_steps = 0;
     const long long T = block_steps_per_wave(raw, G, W, waves, hot_len, &hot_steps);
-    std::vector<Visit> visits; // the ordinary ones
-    visits.reserve(raw.size());
+    std::vector<Visit> ordinary[2]; // the ordinary ones, by role
+    ordinary[0].reserve(raw.size());
     std::vector<Piece> pieces[2]; // by role
     for (size_t i = 0; i < raw.size(); ++i) {
         const Visit &v = raw[i];
-        if (!v.swapped && (long long)v.len <= hot_len) {
-            visits.push_back(v);
+        if ((long long)v.len <= hot_len) {
+            ordinary[v.swapped ? 1 : 0].push_back(v);
             continue;
         }
         out.hot++;
@@ -241,10 +241,10 @@ static void pack_block(std::vector<Visit> &raw, int G, int W, int waves, int tar
         if (pc.empty()) continue;
         long long steps = 0;
         for (const Piece &q : pc) steps += q.steps;
-        long long nt = std::max<long long>(1, (steps + T / 2) / T);
+        long long nt = std::max<long long>(1, (steps + T - 1) / T);
         nt = std::min<long long>(nt, (long long)pc.size());
-        // leave the ordinary rows at least half of the workgroups
-        nt = std::min<long long>(nt, std::max(1, wgs_total / 2 - wgs_used));
+        // (the ordinary rows keep at least one workgroup)
+        nt = std::min<long long>(nt, std::max(1, wgs_total - 1 - wgs_used));
         std::stable_sort(pc.begin(), pc.end(), [](const Piece &a, const Piece &b) { return a.steps > b.steps; });
         std::vector<long long> load((size_t)nt, 0);
         std::vector<std::vector<uint32_t>> of((size_t)nt);
@@ -311,24 +311,40 @@ static void pack_block(std::vector<Visit> &raw, int G, int W, int waves, int tar
         }
         wgs_used += (int)nt;
     }
-    if (visits.empty()) return;
-    // longest first, equal lengths in their given order: a counting sort (lengths are at most hot_len)
-    uint32_t max_len = 0;
-    for (const Visit &v : visits) max_len = std::max(max_len, v.len);
-    {
-        std::vector<size_t> at((size_t)max_len + 2, 0);
-        for (const Visit &v : visits) at[(size_t)(max_len - v.len) + 1]++;
-        for (size_t i = 1; i < at.size(); ++i) at[i] += at[i - 1];
-        std::vector<Visit> sorted(visits.size());
-        for (const Visit &v : visits) sorted[at[(size_t)(max_len - v.len)]++] = v;
-        visits.swap(sorted);
-    }
+    // The ordinary rows: wave tasks, one class per role.  The waves that the workgroup tasks leave are dealt over the two roles
+    // in proportion to their ratings.
     const int waves_main = std::max(std::min(W, waves), waves - W * wgs_used);
-    if (tasks_per_wave > 0) { // equal-load tasks, (tasks per wave) x (waves left for the ordinary rows) of them
-        pack_class(visits, 0, visits.size(), G, 8, out, (long long)tasks_per_wave * waves_main);
-        return;
+    long long L_role[2] = {0, 0};
+    for (int role = 0; role < 2; ++role)
+        for (const Visit &v : ordinary[role]) L_role[role] += v.len;
+    for (int role = 0; role < 2; ++role) {
+        std::vector<Visit> &visits = ordinary[role];
+        if (visits.empty()) continue;
+        // longest first, equal lengths in their given order: a counting sort (lengths are at most hot_len)
+        uint32_t max_len = 0;
+        for (const Visit &v : visits) max_len = std::max(max_len, v.len);
+        {
+            std::vector<size_t> at((size_t)max_len + 2, 0);
+            for (const Visit &v : visits) at[(size_t)(max_len - v.len) + 1]++;
+            for (size_t i = 1; i < at.size(); ++i) at[i] += at[i - 1];
+            std::vector<Visit> sorted(visits.size());
+            for (const Visit &v : visits) sorted[at[(size_t)(max_len - v.len)]++] = v;
+            visits.swap(sorted);
+        }
+        const size_t t_first = out.tasks.size();
+        if (tasks_per_wave > 0) { // equal-load tasks, (tasks per wave) x (waves of this role) of them
+            long long wr = waves_main;
+            if (L_role[1 - role] > 0)
+                wr = std::max<long long>(1, std::min<long long>(waves_main - 1, (waves_main * L_role[role] + (L_role[0] + L_role[1]) / 2) / (L_role[0] + L_role[1])));
+            pack_class(visits, 0, visits.size(), G, 8, out, (long long)tasks_per_wave * wr);
+        } else {
+            pack_class(visits, 0, visits.size(), G, std::max(8, target), out); // explicit task_steps (tests): tasks of that size
+        }
+        for (size_t t = t_first; t < out.tasks.size(); ++t) out.tasks[t].pad = (uint32_t)role;
+        if (role) // (the lists of these tasks are visits of rows of the gathered side)
+            for (Placement &pl : out.places)
+                if (pl.dst >= out.tasks[t_first].off && (pl.stride_flags & 0x40000000u)) pl.stride_flags |= 0x80000000u;
     }
-    pack_class(visits, 0, visits.size(), G, std::max(8, target), out); // explicit task_steps (tests): tasks of that size
 }
 
 void plan_sizes(long long nnz, int NB, int G, const PlanConfig &cfg, int &target, int &hot_len)
@@ -353,11 +369,12 @@ void plan_hot_gathered(const PlanConfig &cfg, Plan &p)
     // A gathered row is read-modified-written by whatever lists hold one of its ratings at the moment; a row with more
     // ratings in a block than one list holds is, on average, in several lists at once and loses most of its updates (and
     // of its accumulator growth: its steps stay too large -- round 2 traced configs[2]'s -2 % to exactly these rows).
-    // EXPERIMENTAL (mfx_options.swap_heavy, off by default): such rows are taken out of the lock-free side -- their ratings
-    // are grouped by THEM and run in workgroup tasks with the roles swapped.  As long as those tasks run beside the wave
-    // tasks, an owner row that a wave task holds in registers is written back over what a swapped visit did to it
-    // meanwhile (order emulation, 20 k x 400 k case: +4.0 % against +1.0 % without), so this waits for a launch in two
-    // phases.  The test uses the row's global count (a block holds about 1/NS of it: the stripes have equal
+    // Such rows are taken out of the lock-free side: their ratings are grouped by THEM and run in workgroup tasks with the
+    // roles swapped (mfx_options.no_swap switches it off).  Those visits read-modify-write owner rows while a wave task may
+    // hold them in registers, so with such a plan every visit writes back what memory holds at its end plus what it
+    // changed, not its copy (kernels.hip: merge_back; without that an owner row kept for most of a launch -- 20 k x 400 k:
+    // 80 % of the time -- lost what the swapped visits did to it: +4.0 % against +1.0 % in the order emulation).
+    // The test uses the row's global count (a block holds about 1/NS of it: the stripes have equal
     // mass), so it can be made per rating before anything is sorted: swapped iff the gathered row is heavy and heavier
     // than the rating's owner row.
     int target, hot_len;
@@ -366,8 +383,10 @@ void plan_hot_gathered(const PlanConfig &cfg, Plan &p)
     p.waves_per_wg = std::max(1, std::min(4, cfg.waves_per_wg));
     const std::vector<int> &og = p.owner_is_q ? p.omega_p : p.omega_q;
     p.hot_gat.assign(og.size(), 0);
-    if (!cfg.swap_heavy) return;
+    p.swap_heavy = cfg.swap_heavy;
+    if (!cfg.swap_heavy) return; // (mfx_options.no_swap)
     const long long thr = (long long)hot_len * p.ns;
+    p.heavy_thr = thr;
     for (size_t i = 0; i < og.size(); ++i) p.hot_gat[i] = (long long)og[i] > thr ? 1 : 0;
 }
 
@@ -409,7 +428,7 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
                 if (b >= NB) break;
                 const long long T = block_steps_per_wave(block_visits[b], G, W, waves, hot_len);
                 for (const Visit &v : block_visits[b])
-                    if ((v.swapped || (long long)v.len > hot_len) && visit_copies(v.len, (long long)W * G, T) > 1)
+                    if ((long long)v.len > hot_len && visit_copies(v.len, (long long)W * G, T) > 1)
                         cut[b].push_back(v.own | (v.swapped ? 0x80000000u : 0u));
             }
         };
@@ -689,7 +708,7 @@ void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cf
         for (long long i = b; i < e; ++i) {
             uint32_t u = (uint32_t)p.p_map[R[i].u], v = (uint32_t)p.q_map[R[i].v];
             const uint32_t own = p.owner_is_q ? v : u, gat = p.owner_is_q ? u : v;
-            const bool sw = p.hot_gat[gat] && omega_gat[gat] > omega_own[own];
+            const bool sw = p.swap_heavy && omega_gat[gat] > omega_own[own];
             Rat x;
             x.own = sw ? gat : own;
             x.gat = sw ? own : gat;
@@ -752,11 +771,25 @@ void build_plan(const Node *R, long long nnz, int m, int n, const PlanConfig &cf
             const uint32_t stride = pl.stride_flags & 0xFFFFu;
             const uint32_t flags = (pl.stride_flags >> 31) ? ENTRY_SWAPPED : 0u;
             const bool visit_start = ((pl.stride_flags >> 30) & 1u) != 0;
+            // the (block, role) bucket of the sorted array this placement reads from
+            const size_t bk = (size_t)(std::upper_bound(bptr.begin(), bptr.end(), (long long)pl.src) - bptr.begin()) - 1;
+            const uint64_t bk_lo = (uint64_t)bptr[bk], bk_hi = (uint64_t)bptr[bk + 1];
             for (uint32_t x = 0; x < pl.len; ++x) {
-                const Rat &rr = sorted[pl.src + (uint64_t)x * stride];
+                const uint64_t si = pl.src + (uint64_t)x * stride;
+                const Rat &rr = sorted[si];
                 Entry &en = p.entries[pl.dst + (uint64_t)x * G];
                 en.own = rr.own | flags | ((visit_start && x == 0) ? 0x80000000u : 0u);
                 en.gat = (int32_t)rr.gat;
+                // A long run of ONE pair of two heavy rows.  The lighter row of the pair lives in the LDS of its own workgroup
+                // visits during the launch; a run that read-modify-writes it in memory as well is a second stream that
+                // converges by itself, and the two changes are added: the row overshoots (eta = 0.2 overflowed that way).
+                // Inside such a run the rating moves the heavier row only (ENTRY_READ_ONLY).  (Both neighbours belong to the
+                // same block and role: a pair does not repeat across them.)
+                if (p.swap_heavy && (flags ? (long long)omega_own[rr.gat] > p.heavy_thr : p.hot_gat[rr.gat] != 0) &&
+                    si >= bk_lo + RUN_READ_ONLY / 2 && si + RUN_READ_ONLY / 2 < bk_hi) {
+                    const Rat &lo = sorted[si - RUN_READ_ONLY / 2], &hi = sorted[si + RUN_READ_ONLY / 2];
+                    if (lo.own == rr.own && lo.gat == rr.gat && hi.own == rr.own && hi.gat == rr.gat) en.gat |= ENTRY_READ_ONLY;
+                }
                 en.r = rr.r;
             }
         }

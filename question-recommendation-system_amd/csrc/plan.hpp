@@ -25,6 +25,12 @@ struct Node { int u; int v; float r; }; // = mf_node (reference mf/mf.h:36-41)
 // row lives on the plan's GATHERED side -- `own` then indexes the gathered side's factors and `gat` the owner side's.
 struct Entry { uint32_t own; int32_t gat; float r; };
 constexpr uint32_t ENTRY_SWAPPED = 0x40000000u, ENTRY_ID_MASK = 0x3FFFFFFFu;
+// Bit 30 of `gat` (ENTRY_READ_ONLY): this rating is inside a long run of ONE pair of two heavy rows (synthetic streams repeat
+// a pair -- heavy user, heavy item -- thousands of times).  The lighter row of the pair lives in the LDS of its own workgroup
+// visits during the launch; the run moves the heavier row only (plan.cpp, build_plan).  RUN_READ_ONLY: a rating is "inside" a
+// run when the ratings RUN_READ_ONLY / 2 places before and after it in the sorted order are the same pair.
+constexpr int32_t ENTRY_READ_ONLY = 0x40000000;
+constexpr int RUN_READ_ONLY = 64;
 static_assert(sizeof(Entry) == 12, "Entry must stay 12 bytes (mf_node sized)");
 
 // One wavefront task: `nsteps` steps of G = 64/lanes ratings, stored step-major
@@ -116,7 +122,9 @@ struct Plan {
     std::vector<long long> slot_wg_ptr;   // ns*ns+1
     int waves_per_wg = 4;
     int hot_len = 128;                    // a row with more ratings in a block goes to a workgroup task
+    bool swap_heavy = false;              // heavy rows of the gathered side run with the roles swapped (PlanConfig::swap_heavy)
     std::vector<char> hot_gat;            // per internal row of the gathered side: heavy by its global count (roles swapped)
+    long long heavy_thr = 0;              // ... = more than this many ratings in all (hot_len per block on average)
     long long n_hot_slots = 0;            // rows that are split over several workgroups somewhere (combine slots)
     std::vector<int> hot_rows;            // combine slot -> internal row | side << 31 (1 = gathered side of the plan)
     std::vector<char> round_hot;          // ns flags: does round r hold a split row (is there anything to fold behind it)?

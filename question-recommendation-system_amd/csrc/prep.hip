@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const Node *R, long long nnz
 __global__ __launch_bounds__(256) void key_build(const Node *R, long long nnz, const int *p_map,
                                                  const int *q_map, int owner_is_q, float inv_scale,
                                                  int do_scale, const int *bounds, int ns, const int *omega_own,
-                                                 const int *omega_gat, const char *hot_gat,
+                                                 const int *omega_gat, int swap_heavy,
                                                  unsigned long long *keys, float *vals)
 {
     __shared__ int sb[2 * 257];
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void key_build(const Node *R, long long nnz, c
         const unsigned own = owner_is_q ? v : u, gat = owner_is_q ? u : v;
         const unsigned long long blk =
             (unsigned long long)stripe_of(own_begin, ns, own) * ns + stripe_of(gat_begin, ns, gat);
-        const bool sw = hot_gat[gat] && omega_gat[gat] > omega_own[own];
+        const bool sw = swap_heavy && omega_gat[gat] > omega_own[own];
         keys[i] = (blk << (2 * ID_BITS + 1)) | ((unsigned long long)(sw ? 1 : 0) << (2 * ID_BITS)) |
                   ((unsigned long long)(sw ? gat : own) << ID_BITS) | (sw ? own : gat);
         vals[i] = do_scale ? x.r * inv_scale : x.r;
@@ -158,9 +158,11 @@ __global__ __launch_bounds__(256) void fill_entries(EntryD *e, long long n)
 }
 
 // one lane per placement: entries[dst + x*G] <- sorted rating src + x*stride (plan.hpp: Placement)
+// omega_own / hot_gat / heavy_thr: the read-only rule of plan.cpp (a pair of two heavy rows moves the heavier one only)
 __global__ __launch_bounds__(256) void emit_entries(const Placement *pl, long long npl,
-                                                    const unsigned long long *keys, const float *vals,
-                                                    int G, EntryD *entries)
+                                                    const unsigned long long *keys, const float *vals, long long nnz,
+                                                    int G, const int *omega_own, const char *hot_gat, long long heavy_thr,
+                                                    int swap_heavy, EntryD *entries)
 {
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nth = (long long)gridDim.x * blockDim.x;
@@ -170,10 +172,16 @@ __global__ __launch_bounds__(256) void emit_entries(const Placement *pl, long lo
         const unsigned flags = (p.stride_flags >> 31) ? ENTRY_SWAPPED : 0u;
         const bool visit_start = ((p.stride_flags >> 30) & 1u) != 0;
         for (unsigned x = 0; x < p.len; ++x) {
-            const unsigned long long k = keys[p.src + (unsigned long long)x * stride];
+            const unsigned long long si = p.src + (unsigned long long)x * stride;
+            const unsigned long long k = keys[si];
             EntryD e;
             e.own = (unsigned)((k >> ID_BITS) & ((1u << ID_BITS) - 1)) | flags | ((visit_start && x == 0) ? 0x80000000u : 0u);
             e.gat = (int)(k & ((1u << ID_BITS) - 1));
+            // inside a long run of one pair of two heavy rows (plan.cpp, build_plan): the key holds block, role and both ids
+            if (swap_heavy && (flags ? (long long)omega_own[e.gat] > heavy_thr : hot_gat[e.gat] != 0) &&
+                si >= (unsigned long long)(RUN_READ_ONLY / 2) && si + RUN_READ_ONLY / 2 < (unsigned long long)nnz &&
+                keys[si - RUN_READ_ONLY / 2] == k && keys[si + RUN_READ_ONLY / 2] == k)
+                e.gat |= ENTRY_READ_ONLY;
             e.r = vals[p.src + (unsigned long long)x * stride];
             entries[p.dst + (unsigned long long)x * G] = e;
         }
@@ -368,7 +376,7 @@ void build_plan_device(const void *dR_v, long long nnz, int m, int n, const Plan
     lap("maps H2D + key buffers");
     hipLaunchKernelGGL(key_build, dim3(grid_of(nnz, cu_count)), dim3(256), 0, s, dR, nnz, dPmap.p, dQmap.p,
                        p.owner_is_q ? 1 : 0, p.inv_scale, p.inv_scale != 1.0f ? 1 : 0, dBounds.p, NS, dOmOwn.p, dOmGat.p,
-                       dHotGat.p, dKeyA.p, dValA.p);
+                       p.swap_heavy ? 1 : 0, dKeyA.p, dValA.p);
 
     lap("keys");
     // 3. sort by (block, owner, gathered); stable, so equal pairs keep their input order
@@ -468,7 +476,8 @@ void build_plan_device(const void *dR_v, long long nnz, int m, int n, const Plan
         PREP_TRY(hipMemcpyAsync(dPlaces.p, places.data(), places.size() * sizeof(Placement), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(fill_entries, dim3(grid_of(p.n_entries, cu_count)), dim3(256), 0, s, dEntries, p.n_entries);
         hipLaunchKernelGGL(emit_entries, dim3(grid_of((long long)places.size(), cu_count)), dim3(256), 0, s,
-                           dPlaces.p, (long long)places.size(), dKeyB.p, dValB.p, G, dEntries);
+                           dPlaces.p, (long long)places.size(), dKeyB.p, dValB.p, nnz, G, dOmOwn.p, dHotGat.p, (long long)p.heavy_thr,
+                           p.swap_heavy ? 1 : 0, dEntries);
         PREP_TRY(hipGetLastError());
         PREP_TRY(hipStreamSynchronize(s));
         lap("placements H2D + entries");

@@ -229,7 +229,7 @@ static mfx::PlanConfig plan_config(const mfx_options &opt, int stripes, int wgs_
     cfg.stats_std = opt.stats_std;
     cfg.waves_per_stripe = wgs_per_xcd * waves_per_wg;
     cfg.waves_per_wg = waves_per_wg;
-    cfg.swap_heavy = opt.swap_heavy != 0 || knob_int("MFX_SWAP_HEAVY", 0) != 0;
+    cfg.swap_heavy = opt.no_swap == 0 && knob_int("MFX_NO_SWAP", 0) == 0;
     cfg.threads = g_host_threads;
     return cfg;
 }
@@ -681,6 +681,7 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
         HIP_TRY(hipEventRecord(e0, s));
     }
     a.warm = t->warm;
+    a.merge_back = p.swap_heavy ? 1 : 0;
     a.waves_per_xcd = t->wgs_per_xcd * t->waves_per_wg;
     for (int i = i_begin; i < i_end; ++i) {
         const int r = (int)((i + t->epochs_done) % ns); // rotate the starting round per epoch

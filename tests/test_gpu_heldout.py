@@ -24,7 +24,7 @@ RMSE_RTOL = 0.02
 HELD = json.load(open(os.path.join(HERE, "golden", "heldout.json")))
 
 
-STRESS = {"zipf11dup": 0.10}  # reported, not held to the tolerance (tests/heldout_data.py says why): sanity bound only
+STRESS = {"zipf11dup": 0.15}  # reported, not held to the tolerance (tests/heldout_data.py says why): sanity bound only
 
 
 @pytest.mark.parametrize("name", list(heldout_data.CASES))

@@ -391,7 +391,7 @@ def test_workgroup_visit_equals_the_emulation(pkg, orc, k):
     for it in range(3):
         t.epoch(slow_only=(it == 0)); got.append(t.last_loss())
     P, Q, PG, QG = t.get_model(); t.close()
-    np.testing.assert_allclose(got, loss, rtol=1e-5 if exact else 5e-3)
+    np.testing.assert_allclose(got, loss, rtol=1e-5 if exact else 3e-2)
     for a_, b_ in ((Q, Qe), (QG, QGe), (P, Pe), (PG, PGe)):
         np.testing.assert_allclose(a_, b_, rtol=2e-4 if exact else 3e-2, atol=2e-5 if exact else 3e-3)
 

@@ -48,26 +48,36 @@ def check_plan(pkg, orc, R, m, n, k, **kw):
     assert G * v.lanes_per_rating == 64 and v.lanes_per_rating * 4 >= v.k_aligned and 1 <= W <= 4
     act = e["gat"] >= 0
     assert (e["gat"] >= -1).all()  # ratings and padding, nothing else
+    ro = act & ((e["gat"] & pkg.ENTRY_READ_ONLY) != 0)  # bit 30 of gat: that row is read, not written (a pair of two heavy rows)
     assert act.sum() == len(R) and v.n_padding == len(e) - len(R)
     # every rating exactly once, relabelled and scaled exactly as shuffle/scale_problem do.  In a workgroup task of a
     # heavy GATHERED row (bit 30 of `own`) the two ids have changed places.
     Ri = internal(R, hp, orc)
     swp = ((e["own"] & pkg.ENTRY_SWAPPED) != 0)
     a_id = (e["own"] & pkg.ENTRY_ID_MASK).astype(np.int64)
-    b_id = e["gat"].astype(np.int64)
+    b_id = np.where(act, e["gat"] & pkg.ENTRY_ID_MASK, -1).astype(np.int64)
     own_id, gat_id = np.where(swp, b_id, a_id), np.where(swp, a_id, b_id)  # ids on the plan's owner / gathered side
     u, vv = (gat_id, own_id) if v.owner_is_q else (own_id, gat_id)
     got = np.stack([u[act], vv[act], e["r"][act].view(np.uint32).astype(np.int64)], 1)
     want = np.stack([Ri["u"].astype(np.int64), Ri["v"].astype(np.int64), Ri["r"].view(np.uint32).astype(np.int64)], 1)
     assert np.array_equal(got[np.lexsort(got.T[::-1])], want[np.lexsort(want.T[::-1])])
-    # which ratings run with the roles swapped: the gathered row is heavy by its global count (more than hot_len ratings
-    # per block on average) and heavier than the rating's owner row -- and no others
+    # which ratings run with the roles swapped: those whose gathered row has more ratings than their owner row (every
+    # rating is worked from its heavier row; the lighter one is the one that is read-modified-written) -- and no others
     om_o, om_g = (hp.omega_q, hp.omega_p) if v.owner_is_q else (hp.omega_p, hp.omega_q)
-    rule = (om_g[gat_id[act]] > v.hot_len * NS) & (om_g[gat_id[act]] > om_o[own_id[act]])
-    if kw.get("swap_heavy"):
-        assert np.array_equal(rule, swp[act])
+    rule = om_g[gat_id[act]] > om_o[own_id[act]]
+    if kw.get("no_swap"):
+        assert not swp.any() and not ro.any()
     else:
-        assert not swp.any()
+        assert np.array_equal(rule, swp[act])
+        # read-only: inside a long run of ONE pair whose read-modify-write side is a heavy row itself (it has workgroup visits
+        # of its own in this launch) -- at least RUN_READ_ONLY + 1 = 65 repeats of the pair, and only such pairs
+        heavy_rmw = np.where(swp[act], om_o[own_id[act]] > v.hot_len * NS, om_g[gat_id[act]] > v.hot_len * NS)
+        assert not (ro[act] & ~heavy_rmw).any()
+        if ro.any():
+            pair = own_id[act] * (max(m, n) + 1) + gat_id[act]
+            up, cnt = np.unique(pair, return_counts=True)
+            rep = cnt[np.searchsorted(up, pair)]
+            assert (rep[ro[act]] >= 65).all()  # (the first and the last 32 ratings of a run stay writable)
     # wave tasks and workgroup tasks together tile the entry array; step-major, G entries per step and wave
     assert sptr[0] == 0 and sptr[-1] == len(tasks) and (np.diff(sptr) >= 0).all()
     assert wptr[0] == 0 and wptr[-1] == len(wgt) and (np.diff(wptr) >= 0).all()
@@ -122,7 +132,7 @@ def check_plan(pkg, orc, R, m, n, k, **kw):
                     assert all(per_list[l, :cnt[l]].all() for l in range(W * G))   # a list is filled from its first step ...
                     full = int(V["len"]) // ns_v
                     assert (cnt[:full] == ns_v).all() and (cnt[full + 1:] == 0).all()  # ... and the lists one after the other
-                    other = part["gat"].transpose(0, 2, 1).reshape(W * G, ns_v)
+                    other = (part["gat"] & pkg.ENTRY_ID_MASK).transpose(0, 2, 1).reshape(W * G, ns_v)
                     flat = np.concatenate([other[l, :cnt[l]] for l in range(W * G)])
                     assert (np.diff(flat) >= 0).all()                            # in the order of the other side's id
                     key = (int(V["row"]), int(T["swapped"]))
@@ -137,8 +147,14 @@ def check_plan(pkg, orc, R, m, n, k, **kw):
             # a heavy owner row is in workgroup tasks only: what is left in the wave tasks has at most hot_len ratings
             widx = np.concatenate([np.arange(lo, lo + ln) for lo, ln in rng_[: sptr[i + 1] - sptr[i]]]) if sptr[i + 1] > sptr[i] else np.zeros(0, np.int64)
             widx = widx[act[widx]] if len(widx) else widx
-            if len(widx):
-                assert np.bincount(a_id[widx]).max() <= v.hot_len and not swp[widx].any()
+            if len(widx):  # ... per role (a wave task holds visits of ONE side's rows, tasks["pad"] says which)
+                for role in (0, 1):
+                    wr = widx[swp[widx] == bool(role)]
+                    assert len(wr) == 0 or np.bincount(a_id[wr]).max() <= v.hot_len
+            for t in range(sptr[i], sptr[i + 1]):
+                lo_, n_ = int(tasks["off"][t]), int(tasks["nsteps"][t]) * G
+                ta = act[lo_: lo_ + n_]
+                assert (swp[lo_: lo_ + n_][ta] == bool(tasks["pad"][t])).all()
     assert len({tuple(s) for s in slot_of.values()}) == len(slot_of) == v.n_hot_slots  # distinct rows, distinct slots
     # inside every lane-group list of a wave task: an owner change always carries the reload flag, and a list starts with one
     for ti in range(len(tasks)):
@@ -158,14 +174,14 @@ def test_plan_layout_invariants(pkg, orc):
     check_plan(pkg, orc, R, 2500, 1800, 32)
     check_plan(pkg, orc, R, 2500, 1800, 8, stripes=4, task_steps=16)
     check_plan(pkg, orc, R, 2500, 1800, 64, owner_side=1)
-    check_plan(pkg, orc, R, 2500, 1800, 32, swap_heavy=1)
+    check_plan(pkg, orc, R, 2500, 1800, 32, no_swap=1)
     # heavy rows on both sides (the bench generator's 5 % head user and item), wide and narrow rows
     R2 = pkg.synth_host(1, 0, 400000, 9000, 5000)
     for k in (8, 32, 128):
         hp = check_plan(pkg, orc, R2, 9000, 5000, k, task_steps=32)  # (an explicit task size: workgroup tasks even on a small launch)
-        assert hp.view.n_wg_tasks > 0 and (hp.wg_tasks["swapped"] == 0).all()
-        hp = check_plan(pkg, orc, R2, 9000, 5000, k, swap_heavy=1, task_steps=32)
         assert (hp.wg_tasks["swapped"] == 1).any() and (hp.wg_tasks["swapped"] == 0).any()
+        hp = check_plan(pkg, orc, R2, 9000, 5000, k, no_swap=1, task_steps=32)
+        assert hp.view.n_wg_tasks > 0 and (hp.wg_tasks["swapped"] == 0).all()
 
 
 def test_stripes_are_mass_balanced(pkg, orc):
