@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- ratings/s per SGD epoch of the MI355X matrix-factorisation trainer.
 
-  python bench.py --gpus N --steps K --warmup W [--config c2|c1]
+  python bench.py --gpus N --steps K --warmup W [--config c2|c1|c4] [--scaling strong|weak]
   (N > 1 without a launcher: bench.py starts the N ranks itself through torch.distributed.run;
    under a launcher -- WORLD_SIZE set -- it is one of the ranks.)
 
@@ -13,16 +13,24 @@ rating) with ratings, layout and factors resident in HBM.  Workload (config.work
                 100k x 50k, 10 M ratings, k = 32) measured in the same run (N = 1 only).
   c1            configs[1] alone.
 
-With N GPUs each rank trains its own user shard of an (N*m) x n problem (weak scaling, configs[2] per
-GPU); item slots of Q travel round the ring of ranks over RCCL inside the timed region (one writer per
-row, exact SGD -- multi.py); --combine avg selects BASELINE.json's replicate-and-average instead
-(measured to lose the fit).  Epoch 0 (slow_only, 8 of k factors) and the one-off
-pre-processing are outside the timed region, as in SURVEY.md 8(d).
+  c4            BASELINE.json configs[4]: synthetic 10M x 2M, 1 B ratings, k = 128 (fits one MI355X as well).
+
+With N GPUs the SAME workload is split by user range over the ranks (--scaling strong, the default: --gpus 8 with
+the default config IS BASELINE.json configs[3] -- configs[2]'s 100 M ratings over 8 GPUs -- and --config c4 --gpus 8 is
+configs[4]; every rank generates the one stream of the N = 1 line and keeps its users, so N = 1 here equals the
+single-GPU line and the job-wide RMSE is held against the same oracle fixture).  --scaling weak gives every rank
+a user shard of its own (an (N*m) x n problem, configs[2] per GPU: round 2's line).  Item slots of Q travel round the
+ring of ranks over RCCL inside the timed region (one writer per row, exact SGD -- multi.py); --combine avg selects
+BASELINE.json's replicate-and-average instead (measured to lose the fit).  Epoch 0 (slow_only, 8 of k
+factors) and the one-off pre-processing are outside the timed region, as in SURVEY.md 8(d).
 
 Prints ONE JSON line (rank 0): metric/value/unit per the driver contract, plus
-  roofline        algorithmic bytes per launch / mean launch time (HIP events on the launch stream) vs 8 TB/s;
-                  `traffic` = measured bytes per launch between the L2s and the fabric (rocprofv3 PMC passes of
-                  this command, profiles/), and the `l2` block, so a reader sees which level binds
+  roofline        `achieved` = algorithmic bytes per launch (16 k_a + 44 per rating) / mean launch time
+                  (HIP events on the launch stream); `traffic` = measured bytes per launch between the L2s and the
+                  fabric (rocprofv3 PMC passes of this command, profiles/); `frac` = traffic / time / 8 TB/s -- the
+                  fraction of the HBM peak that really moves (<= 1) -- and `algorithmic_frac` the SURVEY figure over
+                  the same time (> 1 when rows stay in registers and caches); the `l2` block shows the level above
+  epoch_ms        min / median / max of the timed epochs (HIP events), and the device clocks the box reports
   rounds_verified every block of every timed launch was worked (mfx_trainer_sync's cursor check)
   matched_rmse    GPU vs the deterministic oracle vs the reference CPU trainer after the SAME number of epochs
   cpu_baseline    the reference CPU trainer (oracle/_ref) on a bounded sample of the workload, timed on this
@@ -45,11 +53,12 @@ import __graft_entry__ as ge  # noqa: E402
 CONFIGS = {
     "c1": dict(name="BASELINE configs[1]", m=100000, n=50000, nnz=10000000, k=32),
     "c2": dict(name="BASELINE configs[2]", m=1000000, n=500000, nnz=100000000, k=64),
+    "c4": dict(name="BASELINE configs[4]", m=10000000, n=2000000, nnz=1000000000, k=128),
 }
 HYPER = dict(lambda_p=0.1, lambda_q=0.1, eta=0.1, seed=1)  # utility_train defaults (mf.cpp:4549-4551)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 L2_PEAK_GBS = 34500.0   # MI355X_MICROARCH.md: aggregate L2 bandwidth
-RMSE_RTOL = 0.02       # the stated parity tolerance (README / DESIGN.md 5; tests/test_gpu_parity.py)
+RMSE_RTOL = 0.03       # the stated parity tolerance (README / DESIGN.md 5; tests/test_gpu_parity.py)
 MATCH_EPOCHS = 12       # epoch count of the matched-RMSE legs (= T(n2) of the CPU timing)
 SAMPLE_NNZ = 20000000   # cpu_baseline sample: the first 20 M ratings of the workload's stream
 
@@ -150,6 +159,23 @@ def cpu_baseline(pkg, cfg, budget_s=60.0):
     return out, (R, rm)
 
 
+def device_clocks():
+    """Clocks the box reports for device 0 (rocm-smi, best effort): a reader can tell a slow box from a regression."""
+    try:
+        out = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                             timeout=20, text=True).stdout
+        d = json.loads(out)
+        card = next(iter(d.values()))
+        return {k_: v for k_, v in card.items() if "sclk" in k_.lower() or "mclk" in k_.lower() or "fclk" in k_.lower()}
+    except Exception as e:
+        return {"unavailable": repr(e)[:80]}
+
+
+def epoch_stats(ms):
+    ms = sorted(ms)
+    return {"min": ms[0], "median": ms[len(ms) // 2], "max": ms[-1], "n": len(ms), "unit": "ms per epoch, HIP events on the launch stream"}
+
+
 def train_rmse(pkg, torch, dev, R_ptr, nnz, m, n, k, epochs, stream):
     """GPU training RMSE (calc_rmse formula) after `epochs` epochs (epoch 0 slow_only) on ratings in HBM."""
     opts = pkg.default_options(k=k, lambda_p2=HYPER["lambda_p"], lambda_q2=HYPER["lambda_q"], eta=HYPER["eta"], device=dev.index)
@@ -179,9 +205,12 @@ def run_single(pkg, torch, dev, cfg, steps, warmup, stream):
         t.epoch(stream=stream)
     torch.cuda.synchronize()
     t.timing_enable(True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]  # (recorded on the launch stream = torch's current one)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    marks[0].record()
+    for i_ in range(steps):
         t.epoch(stream=stream)
+        marks[i_ + 1].record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     t.sync()  # raises if any block of any launch was left unworked (cursor check, sticky across epochs)
@@ -189,21 +218,23 @@ def run_single(pkg, torch, dev, cfg, steps, warmup, stream):
     t.timing_enable(False)
     rmse = t.rmse()
     t.close()
+    per_epoch = [marks[i_].elapsed_time(marks[i_ + 1]) for i_ in range(steps)]
     return dict(R_dev=R_dev, info=info, elapsed=elapsed, launches=launches, kern_ms=kern_ms, final_rmse=rmse,
-                epochs_trained=1 + warmup + steps)
+                epochs_trained=1 + warmup + steps, epoch_ms=epoch_stats(per_epoch))
 
 
 def roofline_block(cfg_name, info, nnz, steps, launches, launch_s, timing_note):
     bytes_per_launch = info.bytes_per_rating * nnz * steps / max(launches, 1)
     achieved = bytes_per_launch / launch_s / 1e9
-    rl = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-          "traffic": None,
+    rl = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "frac_basis": None,
+          "algorithmic_frac": achieved / HBM_PEAK_GBS, "traffic": None,
           "algorithmic_bytes_per_launch": bytes_per_launch, "kernel": "sgd_round<%d>" % info.lanes_per_rating,
           "bytes_per_rating": info.bytes_per_rating, "ratings_per_launch": nnz * steps / max(launches, 1),
           "avg_launch_us": launch_s * 1e6, "launches_timed": launches, "timing": timing_note,
-          "note": "achieved/frac are ALGORITHMIC bytes (16*k_a+44 per rating, SURVEY.md 8d) over time: owner rows kept in "
-                  "registers and L2/Infinity-Cache hits never reach the fabric, so frac can exceed 1 and is not a "
-                  "fraction of HBM traffic -- traffic_frac is"}
+          "note": "achieved / algorithmic_frac: ALGORITHMIC bytes (16*k_a+44 per rating, SURVEY.md 8d) over the measured time -- "
+                  "owner rows kept in registers or LDS and L2/Infinity-Cache hits never reach the fabric, so that figure can "
+                  "exceed 1.  frac: the MEASURED traffic between the L2s and the fabric (rocprofv3 PMC passes of this command, "
+                  "committed under profiles/; bench.py cannot collect counters itself) over the time measured now"}
     pmc = measured_counters(cfg_name)
     if pmc:
         rl["traffic"] = pmc.get("traffic_bytes_per_launch")
@@ -211,21 +242,21 @@ def roofline_block(cfg_name, info, nnz, steps, launches, launch_s, timing_note):
         if rl["traffic"]:
             rl["traffic_GBs"] = rl["traffic"] / launch_s / 1e9
             rl["traffic_frac"] = rl["traffic_GBs"] / HBM_PEAK_GBS
+            rl["frac"], rl["frac_basis"] = rl["traffic_frac"], "measured traffic (%s) / launch time measured now / peak" % pmc["source"]
         if pmc.get("l2_requests_per_launch"):
             l2b = pmc["l2_requests_per_launch"] * 128.0
             rl["l2"] = {"requests_per_launch": pmc["l2_requests_per_launch"], "hit_rate": pmc.get("l2_hit_rate"),
                         "bytes_per_launch_at_128B": l2b, "achieved": l2b / launch_s / 1e9, "peak": L2_PEAK_GBS,
                         "unit": "GB/s", "frac": l2b / launch_s / 1e9 / L2_PEAK_GBS}
+    if rl["frac"] is None:  # no counter summary for this configuration: only the algorithmic figure exists
+        rl["frac"], rl["frac_basis"] = rl["algorithmic_frac"], "algorithmic bytes (no PMC summary committed for this configuration)"
     return rl
 
 
 def spawn_ranks(args):
     """--gpus N without a launcher: start the N ranks as fresh children (this parent never touches the GPU)."""
-    import torch
-    have = torch.cuda.device_count()  # does not initialise the device on this image
-    if have < args.gpus and not args.same_device:
-        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (a 1-GPU result would not be a --gpus %d result)"
-                         % (args.gpus, have, args.gpus))
+    # (the parent stays GPU-free: it does not even count devices -- every rank child checks that its device exists and
+    #  exits non-zero otherwise, so a 1-GPU box cannot produce a line that says --gpus N)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
@@ -240,6 +271,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default=os.environ.get("MFX_BENCH_CONFIG", "c2"), choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the config's ratings split by user range over the ranks (configs[3] / configs[4] of "
+                         "BASELINE.json); weak = the config per GPU, every rank a user shard of its own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] block and the matched-RMSE legs")
     ap.add_argument("--nnz", type=int, default=0, help=argparse.SUPPRESS)
@@ -271,6 +305,9 @@ def main():
         raise SystemExit("bench.py needs a GPU (no HIP device visible)")
     if args.same_device:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py --gpus %d: rank %d has no GPU (%d visible): a smaller job would not be a --gpus %d result"
+                         % (args.gpus, rank, torch.cuda.device_count(), args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # One explicit stream for everything: the trainers' launches (handle passed to mfx_trainer_epoch) and the
@@ -304,8 +341,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "m_per_gpu": m, "n": n, "nnz_per_gpu": nnz, "k": k,
                        "lambda": HYPER["lambda_p"], "eta": HYPER["eta"], "stripes": info.stripes, "combine": None},
-            "final_rmse": r["final_rmse"], "epochs_trained": r["epochs_trained"], "rounds_verified": True,
-            "rmse_rtol": RMSE_RTOL,
+            "final_rmse": r["final_rmse"], "epochs_trained": r["epochs_trained"],
+            "rounds_verified": "mfx_trainer_sync after the timed loop (cursor check of every block of every launch; it raises otherwise)",
+            "rmse_rtol": RMSE_RTOL, "epoch_ms": r["epoch_ms"], "device_clocks": device_clocks(),
             "roofline": roofline_block(args.config, info, nnz, args.steps, r["launches"], launch_s, note),
         }
         gold = golden_full_size()
@@ -345,7 +383,7 @@ def main():
             got1, _ = train_rmse(pkg, torch, dev, r1["R_dev"].data_ptr(), c1["nnz"], c1["m"], c1["n"], c1["k"], MATCH_EPOCHS, stream)
             out["configs1"] = {"workload": "%s: synthetic %dx%d, %d ratings, k=%d" % (c1["name"], c1["m"], c1["n"], c1["nnz"], c1["k"]),
                                "value": c1["nnz"] * args.steps / r1["elapsed"], "unit": "ratings/s",
-                               "ms_per_step": r1["elapsed"] / args.steps * 1e3, "rounds_verified": True,
+                               "ms_per_step": r1["elapsed"] / args.steps * 1e3, "epoch_ms": r1["epoch_ms"],
                                "roofline": roofline_block("c1", r1["info"], c1["nnz"], args.steps, r1["launches"], l1, note),
                                "matched_rmse": {"epochs": MATCH_EPOCHS, "gpu": got1, "oracle": g1,
                                                 "rel_diff_vs_oracle": (got1 - g1) / g1 if g1 else None}}
@@ -353,9 +391,35 @@ def main():
         return
 
     # ---- N > 1: one rank of the job -------------------------------------------------------------------
-    R_dev = torch.empty(nnz * 3, dtype=torch.int32, device=dev)
-    pkg.synth_device(HYPER["seed"], 0, nnz, m, n, R_dev.data_ptr(), None, shard=rank)  # this rank's user shard
-    torch.cuda.synchronize()
+    strong = args.scaling == "strong"
+    if strong:
+        # BASELINE configs[3] / configs[4]: the ONE stream of the N = 1 line, split by user range over the ranks.  Every rank
+        # generates the stream in pieces on its device and keeps the ratings of its own users (ids made local).
+        spec0 = __import__("importlib.util").util.spec_from_file_location("qrs_multi0", os.path.join(ge.PKG_DIR, "multi.py"))
+        multi0 = __import__("importlib.util").util.module_from_spec(spec0)
+        spec0.loader.exec_module(multi0)
+        lo, hi = multi0.user_range(m, world, rank)
+        m_total, nnz_total = m, nnz
+        keep = []
+        piece = 100000000
+        buf = torch.empty(min(piece, nnz) * 3, dtype=torch.int32, device=dev)
+        for first in range(0, nnz, piece):
+            cnt_ = min(piece, nnz - first)
+            pkg.synth_device(HYPER["seed"], first, cnt_, m, n, buf.data_ptr(), None, shard=0)
+            torch.cuda.synchronize()
+            v3 = buf[: cnt_ * 3].view(-1, 3)
+            sel = v3[(v3[:, 0] >= lo) & (v3[:, 0] < hi)].clone()
+            sel[:, 0] -= lo
+            keep.append(sel)
+        del buf
+        R_dev = torch.cat(keep).contiguous().view(-1)
+        del keep
+        m, nnz = hi - lo, R_dev.numel() // 3
+    else:
+        m_total, nnz_total = world * m, world * nnz
+        R_dev = torch.empty(nnz * 3, dtype=torch.int32, device=dev)
+        pkg.synth_device(HYPER["seed"], 0, nnz, m, n, R_dev.data_ptr(), None, shard=rank)  # this rank's user shard
+        torch.cuda.synchronize()
     rotate = args.combine == "rotate"
     if rotate:
         spec = __import__("importlib.util").util.spec_from_file_location("qrs_multi", os.path.join(ge.PKG_DIR, "multi.py"))
@@ -373,7 +437,15 @@ def main():
 
         def final_rmse():
             return t.rmse(all_ranks=True)
+
+        def matched():
+            """the job-wide RMSE after MATCH_EPOCHS epochs from fresh factors (same triples as the N = 1 line when strong)"""
+            t.reinit()
+            for it in range(MATCH_EPOCHS):
+                t.epoch(slow_only=(it == 0), stream=stream)
+            return t.rmse(all_ranks=True)
     else:
+        matched = None
         # (replicas that average Q need the same item layout on every rank: the data-independent one)
         opts = pkg.default_options(k=k, lambda_p2=HYPER["lambda_p"], lambda_q2=HYPER["lambda_q"], eta=HYPER["eta"],
                                    device=local_rank, identity_maps=2)
@@ -453,23 +525,35 @@ def main():
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     rmse = final_rmse()
+    m_rmse = matched() if (matched is not None and strong and not args.no_secondary) else None
     if rank == 0:
         # several trainers share the stream and the ring runs beside them: this rank's wall clock over its launches
         launch_s = elapsed / max(launches, 1)
         note = "N>1: max-over-ranks wall time of the timed region / launches of rank 0 (ring transfers of Q included)"
         out = {
-            "metric": "ratings/sec per SGD epoch", "value": world * nnz * args.steps / elapsed, "unit": "ratings/s",
+            "metric": "ratings/sec per SGD epoch", "value": nnz_total * args.steps / elapsed, "unit": "ratings/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload + " per GPU (users sharded over ranks: an %dx%d problem with %d ratings; "
-                                              "item slots of Q %s over RCCL)" % (world * m, n, world * nnz,
-                                                                                 "rotate round the ranks" if rotate else "averaged"),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (workload + " split by user range over %d GPUs (BASELINE.json's sharded configuration of this "
+                                    "workload; item slots of Q %s over RCCL)" % (world, "rotate round the ranks" if rotate else "averaged"))
+                       if strong else
+                       (workload + " per GPU (users sharded over ranks: an %dx%d problem with %d ratings; "
+                                   "item slots of Q %s over RCCL)" % (m_total, n, nnz_total,
+                                                                      "rotate round the ranks" if rotate else "averaged")),
+                       "m_total": m_total, "nnz_total": nnz_total,
                        "m_per_gpu": m, "n": n, "nnz_per_gpu": nnz, "k": k, "lambda": HYPER["lambda_p"], "eta": HYPER["eta"],
                        "stripes": info.stripes, "combine": args.combine, "exchanges_per_epoch": nsync,
                        "slots_per_rank": t.c if rotate else None},
-            "final_rmse": rmse, "epochs_trained": 1 + args.warmup + args.steps, "rounds_verified": True,
+            "final_rmse": rmse, "epochs_trained": 1 + args.warmup + args.steps,
+            "rounds_verified": "mfx_trainer_sync of every slot trainer after the timed loop", "rmse_rtol": RMSE_RTOL,
             "roofline": roofline_block("n%d" % world, info, nnz, args.steps, launches, launch_s, note),
         }
+        if m_rmse is not None:
+            want = golden_full_size().get(args.config if not args.nnz else "", {}).get("rmse_after", {}).get(str(MATCH_EPOCHS))
+            out["matched_rmse"] = {"epochs": MATCH_EPOCHS, "gpu_job_wide": m_rmse, "oracle": want,
+                                   "rel_diff_vs_oracle": (m_rmse - want) / want if want else None,
+                                   "within_rtol": (abs(m_rmse - want) / want <= RMSE_RTOL) if want else None,
+                                   "oracle_source": "tests/golden/full_size.json: the one-worker oracle on the UNION problem (the same triples)"}
         print(json.dumps(out), flush=True)
     t.close()
     dist.destroy_process_group()

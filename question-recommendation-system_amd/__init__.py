@@ -44,7 +44,7 @@ class Options(C.Structure):
                 ("wg_per_cu", C.c_int), ("task_steps", C.c_int), ("no_swap", C.c_int),
                 ("rk_mode", C.c_int), ("owner_side", C.c_int), ("identity_maps", C.c_int),
                 ("use_stats", C.c_int), ("stats_avg", C.c_float), ("stats_std", C.c_float),
-                ("reserved", C.c_int * 1)]
+                ("conflict_div", C.c_int)]
 
 
 class Info(C.Structure):

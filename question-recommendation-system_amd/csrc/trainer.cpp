@@ -181,7 +181,7 @@ static int wgs_per_xcd_for(const mfx_options &opt, int m, int n, int ns, int cu_
     const bool owner_is_q = opt.owner_side == 0 ? (m >= n) : opt.owner_side == 2;
     const long long n_gat = owner_is_q ? m : n;
     const long long stripe_rows = (n_gat + ns - 1) / ns;
-    const int div = std::max(1, knob_int("MFX_CONFLICT_DIV", 12));
+    const int div = std::max(1, knob_int("MFX_CONFLICT_DIV", opt.conflict_div > 0 ? opt.conflict_div : 32));
     long long waves = stripe_rows / ((long long)div * G);
     // Small stripes: the head of the popularity distribution weighs more the fewer rows share a
     // stripe, and the RMSE gap to the sequential reference grows (+2.0..2.9 % at 2500 rows per stripe,

@@ -289,9 +289,15 @@ class RotatingTrainer:
         self.ring = SlotRing(self.QS, self.slot_elems, world, rank, dist if live else None, backend, c)
         for s, t in enumerate(self.trainers):
             t.bind_model(self.P.data_ptr(), self.q_slice(s).data_ptr(), self.PG.data_ptr(), self.qg_slice(s).data_ptr())
-        for s, t in enumerate(self.trainers):  # P is written S times with the same values (same counts, same stream)
-            t.init_model_counts(cnt_p, cnt_q[s * seg:(s + 1) * seg])
+        self._cnt_p, self._cnt_q = cnt_p, cnt_q
+        self.reinit()
         self.info = i0
+
+    def reinit(self):
+        """Fresh factors (init_model, the reference's stream per original id) and a ring back at step 0."""
+        for s, t in enumerate(self.trainers):  # P is written S times with the same values (same counts, same stream)
+            t.init_model_counts(self._cnt_p, self._cnt_q[s * self.seg:(s + 1) * self.seg])
+        self.ring.t = 0
 
     def _check_layouts(self, live):
         """Trainers that share rows must put every id in the same row: equal stripe counts, identical user maps

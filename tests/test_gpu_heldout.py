@@ -20,7 +20,7 @@ sys.path.insert(0, HERE)
 import heldout_data  # noqa: E402
 
 pytestmark = pytest.mark.gpu
-RMSE_RTOL = 0.02
+RMSE_RTOL = 0.03
 HELD = json.load(open(os.path.join(HERE, "golden", "heldout.json")))
 
 
