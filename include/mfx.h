@@ -232,6 +232,32 @@ void mfx_device_free(void *p);
  * stale rows seen, polls that ran out, CU of the writer, CU of the reader}; a healthy device gives {rounds, 0, 0, a, b}. */
 int mfx_selftest_visibility(int rounds, int *result5);
 
+/* ---- one job over G devices of one node, inside this process (csrc/job.cpp) --------------------------------
+ * What utility_train's worker threads are in the reference (std::thread, mf/mf.cpp:2837-2846, entered from
+ * php_mf/mfWarp.cpp:12-16): the parallelism behind ONE blocking call.  Ratings are sharded by user range over the
+ * devices (P rows never travel); the item factors are cut into G slots that go round the ring of devices --
+ * ncclSend / ncclRecv on one stream and one RCCL communicator per device (ncclCommInitAll), point to point over
+ * xGMI -- so every row has one writer at any time: ordinary SGD, the reference scheduler's rule (mf.cpp:133-141)
+ * across devices.  RCCL is bound at run time (dlopen), only when n_devices > 1.  device_ids: HIP ordinals (NULL = 0 ..
+ * n_devices-1); ordinals that repeat (tests on a one-GPU box) make the slots move by device-to-device copies
+ * instead of RCCL.  n_devices = 1 is the plain trainer.  mf::utility_train takes this path when MFX_DEVICES > 1.
+ * G > 1 over RCCL has not run on hardware yet (one GPU per test box): unmeasured. */
+typedef struct mfx_job mfx_job;
+int mfx_job_create(const mfx_node *R_host, long long nnz, int m, int n, const mfx_options *opt, int n_devices,
+                   const int *device_ids, mfx_job **out);
+int mfx_job_epoch(mfx_job *j, int slow_only);   /* G steps of the ring; asynchronous */
+int mfx_job_sync(mfx_job *j);
+int mfx_job_last_loss(mfx_job *j, double *sum_sq, float *scale);
+int mfx_job_rmse(mfx_job *j, double *rmse);
+int mfx_job_export(mfx_job *j, float *model_arr, long long len);
+void mfx_job_destroy(mfx_job *j);
+const char *mfx_job_last_error(void);
+/* The ring schedule as a pure function (unit-tested on the CPU): at global step `step` device `device` trains
+ * *slot_trained; before that it sends *send_slot (the slot it trained at step-1) to *send_to and receives *recv_slot
+ * -- the one it trains now -- from *recv_from (-1 at step 0 or with one device: nothing moves). */
+int mfx_job_schedule(int n_devices, int step, int device, int *slot_trained, int *send_slot, int *send_to, int *recv_slot,
+                     int *recv_from);
+
 /* Deterministic synthetic ratings: integer-only generator, identical on
  * host and device.  Writes ratings [first, first+count) of shard `shard` of problem `seed`:
  * a shard is one GPU's user range (m users of its own, the n items shared by all shards);

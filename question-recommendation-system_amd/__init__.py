@@ -136,6 +136,16 @@ def lib():
     L.mfx_hostplan_destroy.restype = None
     L.mfx_synth_host.argtypes = [C.c_ulonglong, C.c_ulonglong, ll, ll, i32, i32, vp]
     L.mfx_synth_device.argtypes = [C.c_ulonglong, C.c_ulonglong, ll, ll, i32, i32, vp, vp]
+    L.mfx_job_create.argtypes = [vp, ll, i32, i32, C.POINTER(Options), i32, vp, C.POINTER(vp)]
+    L.mfx_job_epoch.argtypes = [vp, i32]
+    L.mfx_job_sync.argtypes = [vp]
+    L.mfx_job_last_loss.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_float)]
+    L.mfx_job_rmse.argtypes = [vp, C.POINTER(C.c_double)]
+    L.mfx_job_export.argtypes = [vp, vp, ll]
+    L.mfx_job_destroy.argtypes = [vp]
+    L.mfx_job_destroy.restype = None
+    L.mfx_job_last_error.restype = C.c_char_p
+    L.mfx_job_schedule.argtypes = [i32, i32, i32] + [C.POINTER(i32)] * 5
     L.mfx_default_options.argtypes = [C.POINTER(Options)]
     L.mfx_default_options.restype = None
     # mf:: facade (C++ mangled names; the int& of utility_train is a pointer at the ABI)
@@ -457,6 +467,64 @@ class Trainer:
         for it in range(iters):
             self.epoch(slow_only=(it == 0))
         self.sync()
+
+
+def job_schedule(n_devices, step, device):
+    """(slot trained, slot sent, to, slot received, from) of mfx_job_schedule (the ring of csrc/job.cpp)."""
+    v = [C.c_int() for _ in range(5)]
+    rc = lib().mfx_job_schedule(n_devices, step, device, *[C.byref(x) for x in v])
+    if rc != 0:
+        raise MfxError("mfx_job_schedule: %s" % lib().mfx_job_last_error().decode())
+    return tuple(x.value for x in v)
+
+
+class Job:
+    """One job over G devices inside this process (mfx_job_*): what mf::utility_train runs when MFX_DEVICES > 1."""
+
+    def __init__(self, R, m, n, n_devices=1, device_ids=None, opts=None, **kw):
+        self.opts = opts if opts is not None else default_options(**kw)
+        R = np.ascontiguousarray(R, dtype=NODE)
+        ids = None if device_ids is None else np.ascontiguousarray(device_ids, dtype=np.int32)
+        self._h = C.c_void_p()
+        self.m, self.n, self.k = m, n, self.opts.k
+        rc = lib().mfx_job_create(R.ctypes.data, len(R), m, n, C.byref(self.opts), n_devices,
+                                  None if ids is None else ids.ctypes.data, C.byref(self._h))
+        if rc != 0:
+            raise MfxError("mfx_job_create %d: %s" % (rc, lib().mfx_job_last_error().decode()))
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise MfxError("mfx job error %d: %s" % (rc, lib().mfx_job_last_error().decode()))
+
+    def epoch(self, slow_only=False):
+        self._ck(lib().mfx_job_epoch(self._h, 1 if slow_only else 0))
+
+    def train(self, iters):
+        for it in range(iters):
+            self.epoch(slow_only=(it == 0))
+        self._ck(lib().mfx_job_sync(self._h))
+
+    def rmse(self):
+        v = C.c_double()
+        self._ck(lib().mfx_job_rmse(self._h, C.byref(v)))
+        return v.value
+
+    def export(self):
+        ln = 5 + (self.m + self.n) * self.k
+        out = np.empty(ln, dtype=np.float32)
+        self._ck(lib().mfx_job_export(self._h, out.ctypes.data, ln))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().mfx_job_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class HostPlan:

@@ -264,12 +264,84 @@ mf_double calc_rmse(mf_problem *prob, mf_model *model)
 
 // ---- float-array facade ---------------------------------------------------------------
 
+// MFX_DEVICES=g (read once): the blocking call shards the job over g GPUs of the node (mfx_job_*, csrc/job.cpp) -- the
+// place the reference's worker threads have (mf.cpp:2837-2846).  Fewer GPUs visible than asked for: the call fails.
+static const int g_devices = []() {
+    const char *s = getenv("MFX_DEVICES");
+    return (s && *s) ? atoi(s) : 1;
+}();
+
+static float *utility_train_job(float *train_data, int count, const mf_parameter &param, int &lens)
+{
+    std::vector<mfx_node> R((size_t)count);
+    int m = 0, n = 0;
+    for (int i = 0; i < count; ++i) { // read_triplet, reference mf/mf.cpp:3367-3394
+        R[i].u = (int)train_data[3 * (size_t)i];
+        R[i].v = (int)train_data[3 * (size_t)i + 1];
+        R[i].r = train_data[3 * (size_t)i + 2];
+        if (R[i].u < 0 || R[i].v < 0) return nullptr;
+        m = std::max(m, R[i].u + 1);
+        n = std::max(n, R[i].v + 1);
+    }
+    const long long total = 5 + ((long long)m + n) * (long long)param.k;
+    if (total > 2147483647LL) return nullptr;
+    mfx_options opt;
+    mfx_default_options(&opt);
+    opt.k = param.k;
+    opt.lambda_p2 = param.lambda_p2;
+    opt.lambda_q2 = param.lambda_q2;
+    opt.eta = param.eta;
+    std::lock_guard<std::mutex> lock(g_gpu_mutex);
+    mfx_job *job = nullptr;
+    if (mfx_job_create(R.data(), count, m, n, &opt, g_devices, nullptr, &job) != MFX_OK) {
+        std::cerr << "utility_train (MFX_DEVICES=" << g_devices << "): " << mfx_job_last_error() << std::endl;
+        return nullptr;
+    }
+    struct Guard {
+        mfx_job *j;
+        ~Guard() { mfx_job_destroy(j); }
+    } guard{job};
+    if (!param.quiet) printf("%4s%13s\n", "iter", "tr_rmse"); // (the objective column needs one pass over every slot's rows: left out)
+    for (int iter = 0; iter < param.nr_iters; ++iter) {
+        if (mfx_job_epoch(job, iter == 0) != MFX_OK) {
+            std::cerr << "utility_train: " << mfx_job_last_error() << std::endl;
+            return nullptr;
+        }
+        if (!param.quiet) {
+            double loss = 0;
+            float scale = 1;
+            if (mfx_job_last_loss(job, &loss, &scale) != MFX_OK) return nullptr;
+            printf("%4d%13.4f\n", iter, std::sqrt(loss / (double)count * (double)scale * scale));
+            fflush(stdout);
+        }
+    }
+    float *buf = (float *)malloc(sizeof(float) * (size_t)total); // caller frees with free()
+    if (!buf) return nullptr;
+    if (mfx_job_export(job, buf, total) != MFX_OK) {
+        std::cerr << "utility_train: " << mfx_job_last_error() << std::endl;
+        free(buf);
+        return nullptr;
+    }
+    lens = (int)total;
+    return buf;
+}
+
 float *utility_train(float *train_data, int train_triplet_num, double p_l2, double q_l2, int k,
                      int iters, double eta, int &lens)
 {
     lens = 0;
     try {
         if (train_data == nullptr || train_triplet_num <= 0) return nullptr;
+        if (g_devices > 1) {
+            mf_parameter param = mf_get_default_param(); // reference mf/mf.cpp:3508-3513
+            param.lambda_p2 = (mf_float)p_l2;
+            param.lambda_q2 = (mf_float)q_l2;
+            param.k = k;
+            param.nr_iters = iters;
+            param.eta = (mf_float)eta;
+            if (!check_parameter(param)) return nullptr;
+            return utility_train_job(train_data, train_triplet_num, param, lens);
+        }
         // read_triplet, reference mf/mf.cpp:3367-3394, on the device: the float triples are uploaded once and
         // become nodes in HBM (64-bit index: no overflow past 715 M); m, n = largest ids + 1
         mf_problem tr;

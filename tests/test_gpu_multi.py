@@ -241,3 +241,33 @@ def test_rccl_calls_execute_on_one_gpu():
     assert p.exitcode == 0
     res = q.get(timeout=10)
     assert all(res.values()), res
+
+
+def test_job_one_device_is_the_plain_trainer(pkg):
+    """mfx_job_* with one device is the plain trainer: on a problem small enough to run one wave per XCD (nothing
+    lock-free left: the run is deterministic) the exported model is identical, bit for bit."""
+    m, n, nnz, k = 2000, 1500, 120000, 64
+    R = pkg.synth_host(7, 0, nnz, m, n)
+    t = pkg.Trainer(R, m, n, k=k); t.init_model(); t.train(4); want = t.export(); t.close()
+    t = pkg.Trainer(R, m, n, k=k); t.init_model(); t.train(4); again = t.export(); t.close()
+    assert np.array_equal(want.view(np.uint32), again.view(np.uint32))    # (the premise: deterministic at this size)
+    j = pkg.Job(R, m, n, 1, k=k); j.train(4); got = j.export(); rm = j.rmse(); j.close()
+    assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+    assert abs(pkg.rmse_array(got, R) - rm) / rm < 1e-4
+
+
+@pytest.mark.parametrize("G", [2, 3])
+def test_job_ring_on_one_gpu_matches_oracle(pkg, orc, G):
+    """The G-device job with all its logical devices on cuda:0 (slots move by device-to-device copies instead of RCCL:
+    the rehearsal path): sharding by user range, slot trainers over shared P, the ring, the export in original ids --
+    job-wide RMSE against the one-worker oracle on the whole problem, and the exported model scores the same."""
+    m, n, nnz, k, iters = 40000, 30000, 3000000, 32, 8
+    R = pkg.synth_host(3, 0, nnz, m, n)
+    j = pkg.Job(R, m, n, G, device_ids=[0] * G, k=k)
+    j.train(iters)
+    got, arr = j.rmse(), j.export()
+    j.close()
+    want = orc.rmse(R, orc.train(R, m, n, k=k, iters=iters))
+    assert abs(got - want) / want < RMSE_RTOL, (got, want)
+    assert abs(orc.rmse(R, arr) - got) / got < 1e-4
+    assert arr[:4].tolist() == [0.0, m, n, k]

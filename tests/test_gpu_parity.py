@@ -432,7 +432,7 @@ def test_head_rows_keep_their_updates(pkg, orc):
     heavy owner row: worked by whole workgroups on LDS copies, no update and no Adagrad growth lost (round 1 let the last of
     hundreds of chains overwrite the others: ~1/60 of the growth survived).  Its accumulators match what the plan-order
     emulation accumulates, and both head rows' own error sits near the oracle's."""
-    m, n, nnz, k, iters = 20000, 10000, 2000000, 32, 12
+    m, n, nnz, k, iters = 60000, 30000, 6000000, 32, 12
     R = pkg.synth_host(1, 0, nnz, m, n)
     cu, cv = np.bincount(R["u"], minlength=m), np.bincount(R["v"], minlength=n)
     hu, hv = int(cu.argmax()), int(cv.argmax())

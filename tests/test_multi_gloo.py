@@ -4,6 +4,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -171,3 +172,36 @@ def test_slots_per_rank_rule():
     assert [multi.auto_slots_per_rank(w) for w in (1, 2, 4, 5, 8)] == [2, 2, 2, 1, 1]
     assert multi.slots_for(4, 100000000) == 2 and multi.slots_for(8, 100000000) == 1
     assert multi.slots_for(4, 10000000) == 2 and multi.slots_for(4, 7000000) == 1 and multi.slots_for(2, 3000000) == 1
+
+
+@pytest.mark.parametrize("G", [1, 2, 3, 8])
+def test_job_ring_schedule(G):
+    """mfx_job_schedule (csrc/job.cpp: the ring of the one-process, G-device job behind mf::utility_train): every window of
+    G steps lets every device train every slot once; no two devices hold a slot at the same step (the reference
+    scheduler's rule, mf.cpp:133-141, across devices); what a device receives is exactly what its right neighbour trained
+    the step before -- the slot it is about to train -- so no stale copy is ever trained."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    pkg = ge.import_package()
+    version = {s: 0 for s in range(G)}            # trainings done on the latest copy of every slot
+    held = [{s: 0 for s in range(G)} for _ in range(G)]  # per device: version of its copy of every slot
+    for step in range(3 * G):
+        plan = [pkg.job_schedule(G, step, g) for g in range(G)]
+        # transfers first: what g sends is what g trained at step-1; the receiver gets it from its right neighbour
+        if step > 0 and G > 1:
+            for g, (now, ss, to, rs, frm) in enumerate(plan):
+                assert to == (g - 1) % G and frm == (g + 1) % G
+                assert ss == pkg.job_schedule(G, step - 1, g)[0]          # the slot it trained the step before
+                assert rs == now and plan[frm][1] == rs                   # ... arrives as the slot the receiver trains now
+            for g, (now, ss, to, rs, frm) in enumerate(plan):
+                held[to][ss] = held[g][ss]
+        else:
+            assert all(p[1:] == (-1, -1, -1, -1) for p in plan)
+        slots = [p[0] for p in plan]
+        assert sorted(slots) == list(range(G))                            # one writer per slot at any step
+        for g, s in enumerate(slots):
+            assert held[g][s] == version[s]                               # the copy trained is the latest one
+            version[s] += 1
+            held[g][s] = version[s]
+        if (step + 1) % G == 0:
+            assert len(set(version.values())) == 1                        # a window of G steps = one epoch for every slot
