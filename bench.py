@@ -160,15 +160,19 @@ def cpu_baseline(pkg, cfg, budget_s=60.0):
 
 
 def device_clocks():
-    """Clocks the box reports for device 0 (rocm-smi, best effort): a reader can tell a slow box from a regression."""
-    try:
-        out = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
-                             timeout=20, text=True).stdout
-        d = json.loads(out)
-        card = next(iter(d.values()))
-        return {k_: v for k_, v in card.items() if "sclk" in k_.lower() or "mclk" in k_.lower() or "fclk" in k_.lower()}
-    except Exception as e:
-        return {"unavailable": repr(e)[:80]}
+    """Clocks the box reports for its first GPU (sysfs, best effort; no child process: a process that has initialised the
+    GPU must not exec): a reader can tell a slow box from a regression."""
+    import glob
+    out = {}
+    for name in ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk"):
+        for path in sorted(glob.glob("/sys/class/drm/card*/device/" + name))[:1]:
+            try:
+                lines = [ln.strip() for ln in open(path).read().splitlines() if ln.strip()]
+                cur = [ln for ln in lines if ln.endswith("*")]
+                out[name] = {"current": cur[0].rstrip("* ") if cur else None, "levels": len(lines)}
+            except Exception as e:
+                out[name] = {"unavailable": repr(e)[:60]}
+    return out or {"unavailable": "no /sys/class/drm/card*/device/pp_dpm_* files"}
 
 
 def epoch_stats(ms):

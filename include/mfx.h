@@ -81,6 +81,7 @@ typedef struct mfx_info {
     long long n_hot_slots;           /* rows split over several workgroups somewhere     */
     long long hot_acc_bytes;         /* HBM held by their combine slots                  */
     int waves_per_wg, hot_len;       /* waves of a workgroup that take work; a row with more ratings in a block is heavy */
+    int merge_back;                  /* 1: visits write back memory-now + their change (rows spend much of a launch in registers) */
 } mfx_info;
 
 int mfx_abi_version(void);
@@ -212,6 +213,7 @@ typedef struct mfx_plan_view {
     long long n_wg_tasks, n_wg_visits;
     int waves_per_wg, hot_len;
     const int *hot_rows;            /* combine slot -> internal row | side << 31 (1 = the plan's gathered side)           */
+    int merge_back;                 /* 1: visits write back what memory holds at their end plus what they changed          */
 } mfx_plan_view;
 int mfx_hostplan_build(const mfx_node *R_host, long long nnz, int m, int n,
                        const mfx_options *opt, mfx_hostplan **out);

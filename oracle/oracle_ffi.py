@@ -159,7 +159,7 @@ def plan_order_run(hp, P, Q, PG, QG, epochs, lambda_p=0.1, lambda_q=0.1, eta=0.1
     rc = lib().orc_plan_order_train(ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], ptr[5], ptr[6], v.stripes, v.ratings_per_wave,
                                     v.waves_per_wg, v.k_aligned, v.owner_is_q, P.ctypes.data, Q.ctypes.data, PG.ctypes.data,
                                     QG.ctypes.data, v.n_hot_slots, np.float32(lambda_p) / scale, np.float32(lambda_q) / scale, eta,
-                                    epochs, first_epoch, mode, rsqrt_mode, rk_mode, loss.ctypes.data)
+                                    epochs, first_epoch, mode | (int(v.merge_back) << 8), rsqrt_mode, rk_mode, loss.ctypes.data)
     if rc != 0:
         raise RuntimeError("orc_plan_order_train failed: %d" % rc)
     return loss

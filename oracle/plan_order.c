@@ -79,10 +79,8 @@ int orc_plan_order_train(const void *entries_v, const void *tasks_v, const long 
     float *gsnap = (float *)malloc(sizeof(float) * (size_t)(ka + 2) * (size_t)G);
     /* plans that run heavy rows of the GATHERED side with the roles swapped: those visits read-modify-write owner rows
        while wave tasks hold them in registers, so the wave tasks (and one-copy workgroup visits) write back by merging */
-    for (i = 0; i < (int)slot_wg_ptr[ns * ns]; i++)
-        if (wgt[i].swapped) merge_back = 1;
-    for (i = 0; i < (int)slot_task_ptr[ns * ns]; i++)
-        if (tasks[i].pad) merge_back = 1;
+    merge_back = (mode >> 8) & 1; /* (the plan says whether its visits write back by merging: mfx_plan_view.merge_back) */
+    mode &= 0xFF;
     for (i = 0; i < ns * ns; i++) {
         if (slot_task_ptr[i + 1] - slot_task_ptr[i] > max_tasks) max_tasks = slot_task_ptr[i + 1] - slot_task_ptr[i];
         if (slot_wg_ptr[i + 1] - slot_wg_ptr[i] > max_wg) max_wg = slot_wg_ptr[i + 1] - slot_wg_ptr[i];

@@ -58,7 +58,7 @@ class Info(C.Structure):
                 ("wg_per_cu", C.c_int), ("dP", C.c_void_p), ("dQ", C.c_void_p),
                 ("dPG", C.c_void_p), ("dQG", C.c_void_p), ("bytes_per_rating", C.c_double),
                 ("n_wg_tasks", C.c_longlong), ("n_wg_visits", C.c_longlong), ("n_hot_slots", C.c_longlong),
-                ("hot_acc_bytes", C.c_longlong), ("waves_per_wg", C.c_int), ("hot_len", C.c_int)]
+                ("hot_acc_bytes", C.c_longlong), ("waves_per_wg", C.c_int), ("hot_len", C.c_int), ("merge_back", C.c_int)]
 
 
 class PlanView(C.Structure):
@@ -74,7 +74,7 @@ class PlanView(C.Structure):
                 ("p_begin", C.c_void_p), ("q_begin", C.c_void_p), ("n_hot_slots", C.c_longlong),
                 ("wg_tasks", C.c_void_p), ("wg_visits", C.c_void_p), ("slot_wg_ptr", C.c_void_p),
                 ("n_wg_tasks", C.c_longlong), ("n_wg_visits", C.c_longlong), ("waves_per_wg", C.c_int),
-                ("hot_len", C.c_int), ("hot_rows", C.c_void_p)]
+                ("hot_len", C.c_int), ("hot_rows", C.c_void_p), ("merge_back", C.c_int)]
 
 
 _lib = None

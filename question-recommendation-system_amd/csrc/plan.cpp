@@ -549,6 +549,19 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
     }
     const uint64_t ebase = e_base[NB];
     p.n_entries = (long long)ebase;
+    // With roles per task a row can be read-modified-written by a visit of the other role while a wave task holds it in
+    // registers; the visit then has to write back what memory holds at its end plus what it changed (one more read of the
+    // row per visit: +21 % traffic on configs[2]).  How often that matters is the share of the launch a row spends in
+    // registers: the mean visit length over the steps a wave does.  20 k x 400 k: 80 % (+4.0 % final RMSE without the merge);
+    // configs[2]: 3 % -- there the plain store stays (what is lost is 3 % of the steps of the swapped ratings).
+    {
+        long long nv = 0, lv = 0;
+        for (const TaskDesc &t : p.tasks) lv += (long long)t.nsteps * G;
+        for (int b = 0; b < NB; ++b) nv += (long long)block_visits[b].size();
+        const double mean_visit = nv > 0 ? (double)p.nnz / (double)nv : 0.0;
+        const double steps = p.tasks.empty() ? 1.0 : (double)lv / (double)G / (double)p.tasks.size();
+        p.merge_back = p.swap_heavy && mean_visit > 0.05 * steps;
+    }
     lap("concatenate");
 }
 

@@ -122,7 +122,8 @@ struct Plan {
     std::vector<long long> slot_wg_ptr;   // ns*ns+1
     int waves_per_wg = 4;
     int hot_len = 128;                    // a row with more ratings in a block goes to a workgroup task
-    bool swap_heavy = false;              // heavy rows of the gathered side run with the roles swapped (PlanConfig::swap_heavy)
+    bool swap_heavy = false;              // every rating is worked from its heavier row (roles per task; PlanConfig::swap_heavy)
+    bool merge_back = false;              // visits write back "memory now + what I changed" instead of their copy (finish_plan)
     std::vector<char> hot_gat;            // per internal row of the gathered side: heavy by its global count (roles swapped)
     long long heavy_thr = 0;              // ... = more than this many ratings in all (hot_len per block on average)
     long long n_hot_slots = 0;            // rows that are split over several workgroups somewhere (combine slots)

@@ -183,11 +183,9 @@ static int wgs_per_xcd_for(const mfx_options &opt, int m, int n, int ns, int cu_
     const long long stripe_rows = (n_gat + ns - 1) / ns;
     const int div = std::max(1, knob_int("MFX_CONFLICT_DIV", opt.conflict_div > 0 ? opt.conflict_div : 32));
     long long waves = stripe_rows / ((long long)div * G);
-    // Small stripes: the head of the popularity distribution weighs more the fewer rows share a
-    // stripe, and the RMSE gap to the sequential reference grows (+2.0..2.9 % at 2500 rows per stripe,
-    // +0.5 % with a third of the waves; profiles/experiments/r01_small_stripe_concurrency.log).  Below
-    // 7500 rows the cap therefore falls with the square of the stripe size.  Speed is not at stake there.
-    if (stripe_rows < 7500) waves = waves * stripe_rows / 7500;
+    // (Round 1 cut the cap further, with the square of the stripe size, below 7500 rows per stripe -- at a divisor of 8 .. 12.
+    //  At 32 that rule only pushed 2 M-rating problems down to ONE workgroup per XCD, which then has nobody to run the heavy
+    //  rows' workgroup tasks beside the ordinary rows: +3.2 % on 20 k x 10 k.  It is gone.)
     if (waves < 4) { // tiny problem: one workgroup per XCD with 1..3 live waves
         *waves_per_wg = (int)std::max<long long>(1, waves);
         return 1;
@@ -681,7 +679,7 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
         HIP_TRY(hipEventRecord(e0, s));
     }
     a.warm = t->warm;
-    a.merge_back = p.swap_heavy ? 1 : 0;
+    a.merge_back = p.merge_back ? 1 : 0;
     a.waves_per_xcd = t->wgs_per_xcd * t->waves_per_wg;
     for (int i = i_begin; i < i_end; ++i) {
         const int r = (int)((i + t->epochs_done) % ns); // rotate the starting round per epoch
@@ -834,6 +832,7 @@ int mfx_trainer_info(mfx_trainer *t, mfx_info *o)
     o->hot_acc_bytes = (long long)t->dHotAcc.n * 4;
     o->waves_per_wg = t->waves_per_wg;
     o->hot_len = p.hot_len;
+    o->merge_back = p.merge_back ? 1 : 0;
     o->cu_count = t->cu_count;
     o->xcd_count = t->xcd_count;
     o->wg_per_cu = t->wg_per_cu;
@@ -1252,6 +1251,7 @@ int mfx_hostplan_view(const mfx_hostplan *h, mfx_plan_view *v)
     v->waves_per_wg = p.waves_per_wg;
     v->hot_len = p.hot_len;
     v->hot_rows = p.hot_rows.data();
+    v->merge_back = p.merge_back ? 1 : 0;
     return MFX_OK;
 }
 
