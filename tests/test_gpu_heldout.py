@@ -2,11 +2,14 @@
 (tests/heldout_data.py; expected values = the one-worker oracle's, tests/golden/make_heldout.py -> heldout.json).
 
 Bar: the final training RMSE (calc_rmse formula, reference mf/mf.cpp:4316-4331) after the same number of epochs on the
-same triples within RMSE_RTOL of the oracle's.  The reference's own answer depends on its scheduling parameter nr_bins
-(facade: 20, mf.cpp:4545); the fixture holds it at 8 / 20 / 40 / 100 as well, and on the heavy-head laws it moves by several
-per cent with it alone (zipf11: 0.752 / 0.760 / 0.816 / 0.764).  The GPU result is therefore held to the ENVELOPE of the reference's
-own answers widened by RMSE_RTOL on each side -- for the laws where the reference is self-consistent (uniform, rect, the
-eta x lambda grid) that envelope is one per cent wide and the bar is in effect the tolerance itself.
+same triples within RMSE_RTOL = 3 % of the oracle's (nr_bins 20, the facade's setting) -- the ONE stated tolerance, plain,
+for every law.  Observed with the shipped code: uniform +1.4 .. +1.5 %, zipf11 0.0, rect +2.3 .. +2.4, eta x lambda grid
++0.1 .. +2.1, zipf11_k64 +2.5 .. +2.6 % (profiles/experiments/r03_heldout_gpu.log).  The fixture also holds what the
+reference's own scheduling parameter does to the figure (nr_bins 8 / 40 / 100): it is printed beside the result -- on
+these laws the reference moves by 0.1 .. 2.2 % with it -- but it is not part of the bar.  One case is REPORTED, not held
+to the tolerance: "zipf11dup", where 2 % of the stream is one (user, item) pair repeated 190 000 times; no rating set has
+that, the reference itself moves by 8.5 % with nr_bins on it, and even the sequential meaning of the GPU plan's order sits
+-9.9 % from the oracle (oracle/plan_order.c, mode 2).  It keeps a sanity bound of 15 %.
 """
 import json
 import os
@@ -42,8 +45,8 @@ def test_heldout_law(pkg, orc, name):
     assert abs(orc.rmse(R, arr) - got) / got < 1e-4  # the device-side figure is calc_rmse of the exported model
     ref = sorted(g.get("rmse_bins", {"20": g["rmse"]}).values())
     tol = STRESS.get(name, RMSE_RTOL)
-    lo, hi = ref[0] * (1 - tol), ref[-1] * (1 + tol)
-    print("%s: gpu %.5f  oracle(bins 20) %.5f (%+.2f %%)  reference envelope %.5f .. %.5f" %
+    lo, hi = g["rmse"] * (1 - tol), g["rmse"] * (1 + tol)
+    print("%s: gpu %.5f  oracle(bins 20) %.5f (%+.2f %%)  reference at nr_bins 8/20/40/100: %.5f .. %.5f" %
           (name, got, g["rmse"], (got / g["rmse"] - 1) * 100, ref[0], ref[-1]))
     assert lo < got < hi, (name, got, g["rmse"], ref)
     assert np.isfinite(tr).all() and tr[-1] < tr[1]  # the online error falls (epoch 0 moves eight factors only)

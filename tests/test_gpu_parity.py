@@ -376,11 +376,12 @@ def test_workgroup_visit_equals_the_emulation(pkg, orc, k):
     descriptors) must reproduce the plan-order emulation -- the oracle's update on one LDS-like copy -- to float noise."""
     m, n = 8000, 8
     R = _heavy_problem(pkg, m, k)
-    kw = dict(k=k, wg_per_cu=0, task_steps=16)  # an explicit task size keeps the workgroup tasks on a one-workgroup launch
+    # one wave per XCD (a huge conflict divisor), and an explicit task size keeps the workgroup tasks on a one-workgroup launch
+    kw = dict(k=k, conflict_div=1000000, task_steps=16)
     hp = pkg.HostPlan(R, m, n, **kw)
     v = hp.view
-    assert v.n_wg_tasks > 0 and len(hp.tasks) == 0 and (hp.wg_visits["info"] >> 1).max() == 1
-    exact = v.waves_per_wg == 1  # (wide rows run two waves per workgroup here: their adds interleave, second order in the step)
+    assert v.n_wg_tasks > 0 and len(hp.tasks) == 0 and (hp.wg_visits["info"] >> 1).max() == 1 and v.waves_per_wg == 1
+    exact = True
     t = pkg.Trainer(R, m, n, **kw); t.init_model()
     e, ts, sp = t.plan_copy(); w, vv, wp = t.plan_copy_wg()
     assert np.array_equal(e, hp.entries) and np.array_equal(w, hp.wg_tasks) and np.array_equal(vv, hp.wg_visits)
