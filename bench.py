@@ -215,6 +215,7 @@ def run_single(pkg, torch, dev, cfg, steps, warmup, stream):
     for i_ in range(steps):
         t.epoch(stream=stream)
         marks[i_ + 1].record()
+    clocks = device_clocks()  # read while the queued epochs run (the host only waits here): the clock level under load
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     t.sync()  # raises if any block of any launch was left unworked (cursor check, sticky across epochs)
@@ -224,7 +225,7 @@ def run_single(pkg, torch, dev, cfg, steps, warmup, stream):
     t.close()
     per_epoch = [marks[i_].elapsed_time(marks[i_ + 1]) for i_ in range(steps)]
     return dict(R_dev=R_dev, info=info, elapsed=elapsed, launches=launches, kern_ms=kern_ms, final_rmse=rmse,
-                epochs_trained=1 + warmup + steps, epoch_ms=epoch_stats(per_epoch))
+                epochs_trained=1 + warmup + steps, epoch_ms=epoch_stats(per_epoch), clocks=clocks)
 
 
 def roofline_block(cfg_name, info, nnz, steps, launches, launch_s, timing_note):
@@ -347,7 +348,7 @@ def main():
                        "lambda": HYPER["lambda_p"], "eta": HYPER["eta"], "stripes": info.stripes, "combine": None},
             "final_rmse": r["final_rmse"], "epochs_trained": r["epochs_trained"],
             "rounds_verified": "mfx_trainer_sync after the timed loop (cursor check of every block of every launch; it raises otherwise)",
-            "rmse_rtol": RMSE_RTOL, "epoch_ms": r["epoch_ms"], "device_clocks": device_clocks(),
+            "rmse_rtol": RMSE_RTOL, "epoch_ms": r["epoch_ms"], "device_clocks": r.get("clocks") or device_clocks(),
             "roofline": roofline_block(args.config, info, nnz, args.steps, r["launches"], launch_s, note),
         }
         gold = golden_full_size()
