@@ -19,7 +19,10 @@ def pytest_configure(config):
 def pkg():
     if not os.path.exists(os.path.join(ge.PKG_DIR, "lib", "libmf.so")):
         ge.build()
-    return ge.import_package()
+    p = ge.import_package()
+    if os.environ.get("MFX_TEST_LIB"):  # an experiment build of the library (make variant) under the same tests
+        p.LIB_PATH = os.environ["MFX_TEST_LIB"]
+    return p
 
 
 @pytest.fixture(scope="session")
