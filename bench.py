@@ -60,7 +60,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 L2_PEAK_GBS = 34500.0   # MI355X_MICROARCH.md: aggregate L2 bandwidth
 RMSE_RTOL = 0.03       # the stated parity tolerance (README / DESIGN.md 5; tests/test_gpu_parity.py)
 MATCH_EPOCHS = 12       # epoch count of the matched-RMSE legs (= T(n2) of the CPU timing)
-SAMPLE_NNZ = 20000000   # cpu_baseline sample: the first 20 M ratings of the workload's stream
+SAMPLE_NNZ = 100000000  # cpu_baseline sample: up to 100 M ratings of the workload's stream = the WHOLE of configs[2] (--cpu-sample)
 
 
 def golden_full_size():
@@ -109,14 +109,17 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(pkg, cfg, budget_s=60.0):
-    """Reference CPU epoch rate on this host (iteration-delta) on a bounded sample."""
+def cpu_baseline(pkg, cfg, budget_s=60.0, sample_nnz=SAMPLE_NNZ):
+    """Reference CPU epoch rate on this host (iteration-delta) on a bounded sample: the first `sample_nnz`
+    ratings of the workload's stream -- all of configs[2] by default (about 25 s of CPU work on the bench box's 16 cores; round 2
+    timed a 20 M prefix, which spreads over the full id space and runs the reference three times slower per rating)."""
     orc = ge.import_oracle()
     cores, eff = os.cpu_count() or 1, effective_cores()
     m, n, k = cfg["m"], cfg["n"], cfg["k"]
-    ns = min(SAMPLE_NNZ, cfg["nnz"])
+    ns = min(sample_nnz, cfg["nnz"])
     R = pkg.synth_host(HYPER["seed"], 0, ns, m, n)
-    sample = "first %d ratings of the workload's stream (full %dx%d id space, k=%d)" % (ns, m, n, k)
+    sample = ("the WHOLE workload (%d ratings, %dx%d, k=%d)" if ns == cfg["nnz"] else
+              "first %d ratings of the workload's stream (full %dx%d id space, k=%d)") % (ns, m, n, k)
     if not orc.have_ref():
         # port: one-thread restatement on a 2M-rating prefix
         ns = 2000000
@@ -128,7 +131,7 @@ def cpu_baseline(pkg, cfg, budget_s=60.0):
                 "sample": "first 2M ratings of the workload's stream, oracle C port, T(6 it)-T(2 it)"}, None
     t_start = time.time()
     n1, n2 = 2, MATCH_EPOCHS
-    tmo = 240
+    tmo = 240 + ns // 200000
 
     def delta(threads, bins, a, b):
         # each call runs in a killable child: the reference's shutdown race (quirk Q2) must never cost the line
@@ -141,7 +144,7 @@ def cpu_baseline(pkg, cfg, budget_s=60.0):
     legs = [{"threads": 12, "bins": 20, "ratings_per_s": ns / per if per > 0 else None, "epochs": [n1, n2]}]
     # (ii) short sweep for the reference's best point on this host: nr_bins = max(20, 2*threads+1)
     # (reference mf/mf.cpp:3142, 3177-3181); thread counts up to the cores this process may use
-    for th in (8, 16, 24, 32, 48):
+    for th in (16, 8, 24, 32, 48):
         if th > eff or time.time() - t_start > budget_s:
             continue
         try:
@@ -173,6 +176,19 @@ def device_clocks():
             except Exception as e:
                 out[name] = {"unavailable": repr(e)[:60]}
     return out or {"unavailable": "no /sys/class/drm/card*/device/pp_dpm_* files"}
+
+
+def balanced_user_bounds(torch, cnt_u, world):
+    """Cut the user ids into `world` consecutive ranges of (nearly) equal rating mass; cnt_u = ratings per user."""
+    m = cnt_u.numel()
+    cum = torch.cumsum(cnt_u, 0)
+    total = int(cum[-1].item())
+    want = torch.tensor([(total * r_) // world for r_ in range(1, world)], dtype=torch.int64, device=cnt_u.device)
+    bounds = [0] + [int(x) + 1 for x in torch.searchsorted(cum, want).tolist()] + [m]
+    for i_ in range(1, len(bounds)):  # (strictly increasing, whatever the head rows weigh)
+        bounds[i_] = min(m - (world - i_), max(bounds[i_], bounds[i_ - 1] + 1))
+    bounds[-1] = m
+    return bounds
 
 
 def epoch_stats(ms):
@@ -280,6 +296,8 @@ def main():
                     help="N > 1: strong = the config's ratings split by user range over the ranks (configs[3] / configs[4] of "
                          "BASELINE.json); weak = the config per GPU, every rank a user shard of its own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=SAMPLE_NNZ,
+                    help="ratings of the workload's stream the reference CPU trainer is timed on (default: all of configs[2])")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] block and the matched-RMSE legs")
     ap.add_argument("--nnz", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)  # "gloo": rehearsal of N>1 on one GPU
@@ -364,14 +382,14 @@ def main():
                                    "oracle_source": "tests/golden/full_size.json (one-worker oracle on these exact triples)"}
         if not args.no_cpu_baseline:
             try:
-                base, keep = cpu_baseline(pkg, cfg)
+                base, keep = cpu_baseline(pkg, cfg, sample_nnz=args.cpu_sample)
                 out["cpu_baseline"] = base
                 if keep is not None and not args.no_secondary:
                     # the SAME sample on the GPU for the SAME epochs, next to the reference's and the oracle's value
                     Rs, ref_rm = keep
                     ns = len(Rs)
                     got, _ = train_rmse(pkg, torch, dev, r["R_dev"].data_ptr(), ns, m, n, k, MATCH_EPOCHS, stream)
-                    want = gold.get(args.config + "s", {}).get("rmse_after", {}).get(str(MATCH_EPOCHS)) if not args.nnz else None
+                    want = gold.get(args.config + ("" if ns == nnz else "s"), {}).get("rmse_after", {}).get(str(MATCH_EPOCHS)) if not args.nnz else None
                     out["matched_rmse_sample"] = {"epochs": MATCH_EPOCHS, "nnz": ns, "gpu": got, "reference_cpu": ref_rm,
                                                   "oracle": want,
                                                   "rel_diff_vs_reference": (got - ref_rm) / ref_rm if ref_rm else None,
@@ -403,15 +421,27 @@ def main():
         spec0 = __import__("importlib.util").util.spec_from_file_location("qrs_multi0", os.path.join(ge.PKG_DIR, "multi.py"))
         multi0 = __import__("importlib.util").util.module_from_spec(spec0)
         spec0.loader.exec_module(multi0)
-        lo, hi = multi0.user_range(m, world, rank)
         m_total, nnz_total = m, nnz
-        keep = []
         piece = 100000000
         buf = torch.empty(min(piece, nnz) * 3, dtype=torch.int32, device=dev)
+        # user ranges of equal RATING mass (as mfx_job_create cuts them), not of equal user count: the popular users sit at one
+        # end of the id range and an equal-count cut gives rank 0 a fifth more ratings than the mean.  Every rank computes the
+        # same cuts from the same stream.
+        cnt_u = torch.zeros(m, dtype=torch.int64, device=dev)
         for first in range(0, nnz, piece):
             cnt_ = min(piece, nnz - first)
             pkg.synth_device(HYPER["seed"], first, cnt_, m, n, buf.data_ptr(), None, shard=0)
             torch.cuda.synchronize()
+            cnt_u += torch.bincount(buf[: cnt_ * 3].view(-1, 3)[:, 0].long(), minlength=m)
+        bounds = balanced_user_bounds(torch, cnt_u, world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        del cnt_u
+        keep = []
+        for first in range(0, nnz, piece):
+            cnt_ = min(piece, nnz - first)
+            if nnz > piece or first > 0:  # (one piece: the stream is still in the buffer)
+                pkg.synth_device(HYPER["seed"], first, cnt_, m, n, buf.data_ptr(), None, shard=0)
+                torch.cuda.synchronize()
             v3 = buf[: cnt_ * 3].view(-1, 3)
             sel = v3[(v3[:, 0] >= lo) & (v3[:, 0] < hi)].clone()
             sel[:, 0] -= lo

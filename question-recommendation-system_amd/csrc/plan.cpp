@@ -216,6 +216,26 @@ static void pack_block(std::vector<Visit> &raw, int G, int W, int waves, int tar
     std::vector<Visit> ordinary[2]; // the ordinary ones, by role
     ordinary[0].reserve(raw.size());
     std::vector<Piece> pieces[2]; // by role
+    // A heavy row is cut into pieces of T steps -- unless the block's heavy work does not fit the workgroups there are at T
+    // steps each (a block that is little else than one row: one GPU's slot of a strong split holds such blocks).  Then the
+    // pieces are cut longer, so that they fill the workgroups evenly: 31 pieces of T steps on 30 workgroups make one
+    // workgroup -- and the launch -- take twice as long.
+    const int wgs_total = std::max(1, waves / std::max(1, W));
+    long long Th[2] = {T, T};
+    {
+        long long hs[2] = {0, 0};
+        bool any_ordinary = false;
+        for (const Visit &v : raw) {
+            if ((long long)v.len <= hot_len) any_ordinary = true;
+            else hs[v.swapped ? 1 : 0] += ((long long)v.len + WGL - 1) / WGL;
+        }
+        const long long keep = any_ordinary ? 1 : 0; // (the ordinary rows keep at least one workgroup)
+        const long long cap0 = std::max<long long>(1, wgs_total - keep);
+        Th[0] = std::max(T, (hs[0] + cap0 - 1) / cap0);
+        const long long used0 = hs[0] ? std::min(cap0, (hs[0] + Th[0] - 1) / Th[0]) : 0;
+        const long long cap1 = std::max<long long>(1, wgs_total - keep - used0);
+        Th[1] = std::max(T, (hs[1] + cap1 - 1) / cap1);
+    }
     for (size_t i = 0; i < raw.size(); ++i) {
         const Visit &v = raw[i];
         if ((long long)v.len <= hot_len) {
@@ -223,7 +243,7 @@ static void pack_block(std::vector<Visit> &raw, int G, int W, int waves, int tar
             continue;
         }
         out.hot++;
-        const long long steps = ((long long)v.len + WGL - 1) / WGL, nc = visit_copies(v.len, WGL, T);
+        const long long steps = ((long long)v.len + WGL - 1) / WGL, nc = visit_copies(v.len, WGL, Th[v.swapped ? 1 : 0]);
         const long long per = (steps + nc - 1) / nc; // steps per copy
         uint32_t idx = 0;
         for (long long s0 = 0; s0 < steps; s0 += per, ++idx) {
@@ -235,16 +255,15 @@ static void pack_block(std::vector<Visit> &raw, int G, int W, int waves, int tar
     }
     // workgroup tasks, per role: as many as the heavy work fills at T steps each, the pieces dealt longest first
     int wgs_used = 0;
-    const int wgs_total = std::max(1, waves / std::max(1, W));
     for (int role = 0; role < 2; ++role) {
         std::vector<Piece> &pc = pieces[role];
         if (pc.empty()) continue;
         long long steps = 0;
         for (const Piece &q : pc) steps += q.steps;
-        long long nt = std::max<long long>(1, (steps + T - 1) / T);
+        long long nt = std::max<long long>(1, (steps + Th[role] - 1) / Th[role]);
         nt = std::min<long long>(nt, (long long)pc.size());
         // (the ordinary rows keep at least one workgroup)
-        nt = std::min<long long>(nt, std::max(1, wgs_total - 1 - wgs_used));
+        nt = std::min<long long>(nt, std::max(1, wgs_total - (ordinary[0].empty() && ordinary[1].empty() ? 0 : 1) - wgs_used));
         std::stable_sort(pc.begin(), pc.end(), [](const Piece &a, const Piece &b) { return a.steps > b.steps; });
         std::vector<long long> load((size_t)nt, 0);
         std::vector<std::vector<uint32_t>> of((size_t)nt);
@@ -275,7 +294,7 @@ static void pack_block(std::vector<Visit> &raw, int G, int W, int waves, int tar
             for (uint32_t pi : lst) {
                 const Piece &q = pc[pi];
                 const Visit &v = raw[q.vi];
-                const long long nc = visit_copies(v.len, WGL, T);
+                const long long nc = visit_copies(v.len, WGL, Th[role]);
                 WgVisitRec rec;
                 rec.v.row = v.own;
                 rec.v.nsteps = q.steps;
