@@ -149,8 +149,13 @@ __device__ __forceinline__ void bst_acc(__amdgpu_buffer_rsrc_t r, unsigned off, 
 // LANES  lanes per rating (power of two, LANES*4 >= k_a)
 // FULL   k_a == LANES*4: every lane carries factors (no per-lane bounds test)
 // SLOW   epoch 0 of the reference: only factors [0,8) move (slow_only, mf.cpp:2834, 1230-1231)
+#ifdef MFX_WAVES_PER_EU // experiment (make variant VFLAGS=-DMFX_WAVES_PER_EU=5): ask the register allocator for that occupancy
+#define MFX_OCC __attribute__((amdgpu_waves_per_eu(MFX_WAVES_PER_EU, 8)))
+#else
+#define MFX_OCC
+#endif
 template <int LANES, bool FULL, bool SLOW>
-__global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
+__global__ __launch_bounds__(256) MFX_OCC void sgd_round(RoundArgs a)
 {
     constexpr int G = 64 / LANES;
     constexpr int EBLK = 128; // entries per block of the entry stream (two per lane); EBLK/G steps
@@ -232,6 +237,7 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
             // meaning of the order up to the W x G ratings in flight.  The other side of these ratings is read-modified-
             // written through the XCD's L2 exactly as in a wave task.  With the roles swapped (heavy row of the GATHERED side)
             // the same code runs on the other side's pointers, descriptors and lambda.
+            STAMP(tk1);
             {
                 const long long wbeg = a.slot_wg_ptr[slot];
                 const int nwg = (int)(a.slot_wg_ptr[slot + 1] - wbeg);
@@ -521,6 +527,9 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                 }
             }
             STAMP(tk0);
+#ifdef MFX_STAMPS
+            c_burst += tk0 - tk1; // (diagnostic) cycles this wave spent in the workgroup-task phase
+#endif
             // The first claim of a launch is made once per workgroup, not once per wave: every wave
             // of the XCD asks at the same moment, and atomics on one address take ~70 cycles each.
             __syncthreads(); // (wg_first is reused per slot)
@@ -802,7 +811,6 @@ __global__ __launch_bounds__(256) void sgd_round(RoundArgs a)
                     STAMP(ts3);
 #ifdef MFX_STAMPS
                     c_wait += ts1 - ts0;
-                    if (step < 16) c_burst += ts3 - ts0; // (diagnostic) cycles of the first 16 steps of a task
                     c_win += ts2 - ts1;
                     c_rest += ts3 - ts2;
                     n_steps++;

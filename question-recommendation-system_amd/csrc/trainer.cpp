@@ -654,7 +654,7 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
                     std::sort(st.begin(), st.end());
                     std::sort(en.begin(), en.end());
                     auto q = [](const std::vector<unsigned long long> &v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
-                    fprintf(stderr, "timeline XCC%llu: %zu waves x %.1f steps (first 16 steps of the tasks: %.0f cycles) | start max %llu | end min %llu p10 %llu p50 %llu p90 %llu max %llu (x10 ns)\n",
+                    fprintf(stderr, "timeline XCC%llu: %zu waves x %.1f steps (workgroup-task phase: %.0f cycles per wave) | start max %llu | end min %llu p10 %llu p50 %llu p90 %llu max %llu (x10 ns)\n",
                             x - 1, st.size(), (double)steps / st.size(), (double)burst / std::max<size_t>(1, st.size()), st.back(), en.front(), q(en, .1), q(en, .5), q(en, .9), en.back());
                 }
             }
