@@ -424,7 +424,7 @@ def main():
         m_total, nnz_total = m, nnz
         piece = 100000000
         buf = torch.empty(min(piece, nnz) * 3, dtype=torch.int32, device=dev)
-        # user ranges of equal RATING mass (as mfx_job_create cuts them), not of equal user count: the popular users sit at one
+        # user ranges of equal RATING mass, not of equal user count: the popular users sit at one
         # end of the id range and an equal-count cut gives rank 0 a fifth more ratings than the mean.  Every rank computes the
         # same cuts from the same stream.
         cnt_u = torch.zeros(m, dtype=torch.int64, device=dev)
@@ -462,7 +462,9 @@ def main():
         spec.loader.exec_module(multi)
         t = multi.RotatingTrainer(pkg, R_dev, m, n, world, rank, dist, dev, backend=args.backend,
                                   slots_per_rank=args.slots_per_rank, k=k, lambda_p2=HYPER["lambda_p"],
-                                  lambda_q2=HYPER["lambda_q"], eta=HYPER["eta"], device=local_rank)
+                                  lambda_q2=HYPER["lambda_q"], eta=HYPER["eta"], device=local_rank,
+                                  wide=1 if strong else 0)  # slot trainers of the strong split are small and skewed: wide
+        #                           launches (mfx_options.wide); their parity alone: tests/test_gpu_multi.py, strong_shards.json
         del R_dev
         info = t.info
         nsync = t.S

@@ -62,6 +62,12 @@ typedef struct mfx_options {
                           final RMSE (uniform 100 k x 50 k ids, 12 epochs: +3.4 % at 12, +1.5 % at 32, +1.0 % at 48 -- and the
                           epoch takes 0.74 / 1.9 / 2.8 ms).  Large problems are not touched by it (the occupancy cap binds
                           first); a caller who wants round 2's speed on 10 M-rating problems sets 12.                     */
+    int wide;          /* 1: a WIDE launch -- where the concurrency cap holds a launch below what the chip runs anyway, the idle
+                          workgroups take the heavy rows (the lists of one heavy row and of its copies never meet each other on a
+                          row of the other side).  Twice to four times the speed on skewed 10 M-rating problems (configs[1] 3.7 ->
+                          1.85 ms per epoch at -0.6 % / +0.1 %), but the rows of the other side are updated that much more often per
+                          unit of time and lose accordingly more updates: +6.0 % final RMSE on a Zipf(1.1) law at k = 64 where the
+                          default stays at +2.4 %.  Default 0.  (DESIGN.md "Wide launches")                                        */
 } mfx_options;
 
 typedef struct mfx_info {
@@ -82,6 +88,7 @@ typedef struct mfx_info {
     long long hot_acc_bytes;         /* HBM held by their combine slots                  */
     int waves_per_wg, hot_len;       /* waves of a workgroup that take work; a row with more ratings in a block is heavy */
     int merge_back;                  /* 1: visits write back memory-now + their change (rows spend much of a launch in registers) */
+    int grid_wg_per_cu;              /* workgroups per CU a launch starts (> wg_per_cu: a wide launch, the rest run the heavy rows) */
 } mfx_info;
 
 int mfx_abi_version(void);

@@ -44,7 +44,7 @@ class Options(C.Structure):
                 ("wg_per_cu", C.c_int), ("task_steps", C.c_int), ("no_swap", C.c_int),
                 ("rk_mode", C.c_int), ("owner_side", C.c_int), ("identity_maps", C.c_int),
                 ("use_stats", C.c_int), ("stats_avg", C.c_float), ("stats_std", C.c_float),
-                ("conflict_div", C.c_int)]
+                ("conflict_div", C.c_int), ("wide", C.c_int)]
 
 
 class Info(C.Structure):
@@ -58,7 +58,8 @@ class Info(C.Structure):
                 ("wg_per_cu", C.c_int), ("dP", C.c_void_p), ("dQ", C.c_void_p),
                 ("dPG", C.c_void_p), ("dQG", C.c_void_p), ("bytes_per_rating", C.c_double),
                 ("n_wg_tasks", C.c_longlong), ("n_wg_visits", C.c_longlong), ("n_hot_slots", C.c_longlong),
-                ("hot_acc_bytes", C.c_longlong), ("waves_per_wg", C.c_int), ("hot_len", C.c_int), ("merge_back", C.c_int)]
+                ("hot_acc_bytes", C.c_longlong), ("waves_per_wg", C.c_int), ("hot_len", C.c_int), ("merge_back", C.c_int),
+                ("grid_wg_per_cu", C.c_int)]
 
 
 class PlanView(C.Structure):

@@ -193,19 +193,41 @@ int mfx_job_create(const mfx_node *R, long long nnz, int m, int n, const mfx_opt
     int seg = (n + S - 1) / S;
     seg += (8 - seg % 8) % 8; // rows per slot: a multiple of 8 keeps every slot base 32-byte aligned
     j->seg = seg;
-    const int useg = (m + G - 1) / G;
+    // user ranges of equal RATING mass (consecutive ids): equal counts would give the device that holds the popular users a
+    // fifth more ratings than the mean on a skewed stream, and the ring runs at the pace of the slowest device
+    std::vector<int> ubound((size_t)G + 1, 0);
+    {
+        std::vector<long long> cnt_u((size_t)m, 0);
+        for (long long i = 0; i < nnz; ++i) {
+            const mfx_node &x = R[i];
+            if (x.u < 0 || x.u >= m || x.v < 0 || x.v >= n) return jfail(MFX_E_ARG, "rating with id outside [0,m) x [0,n)");
+            cnt_u[(size_t)x.u]++;
+        }
+        long long cum = 0;
+        int g = 1;
+        for (int u = 0; u < m && g < G; ++u) {
+            cum += cnt_u[(size_t)u];
+            while (g < G && cum >= nnz * g / G) ubound[(size_t)g++] = u + 1;
+        }
+        for (; g < G; ++g) ubound[(size_t)g] = m;
+        ubound[(size_t)G] = m;
+        for (int i = 1; i <= G; ++i) // (strictly increasing while users last, whatever the head rows weigh)
+            ubound[(size_t)i] = std::min(m, std::max(ubound[(size_t)i], std::min(m, ubound[(size_t)i - 1] + 1)));
+        ubound[(size_t)G] = m;
+    }
+    int useg = 1; // the longest range (stripe count of the job)
+    for (int g = 0; g < G; ++g) useg = std::max(useg, ubound[(size_t)g + 1] - ubound[(size_t)g]);
     double s1 = 0, s2 = 0;
     j->cnt_q.assign((size_t)seg * S, 0);
     std::vector<std::vector<mfx_node>> part((size_t)G * S); // (device, slot) -> ratings with local ids
     std::vector<std::vector<int>> cnt_p(G);
-    for (int g = 0; g < G; ++g) cnt_p[g].assign((size_t)std::max(0, std::min(m, (g + 1) * useg) - std::min(m, g * useg)), 0);
+    for (int g = 0; g < G; ++g) cnt_p[g].assign((size_t)(ubound[(size_t)g + 1] - ubound[(size_t)g]), 0);
     for (long long i = 0; i < nnz; ++i) {
         const mfx_node &x = R[i];
-        if (x.u < 0 || x.u >= m || x.v < 0 || x.v >= n) return jfail(MFX_E_ARG, "rating with id outside [0,m) x [0,n)");
         s1 += (double)x.r;
         s2 += (double)x.r * x.r;
-        const int g = x.u / useg, s = x.v / seg;
-        mfx_node y = {x.u - g * useg, x.v - s * seg, x.r};
+        const int g = (int)(std::upper_bound(ubound.begin() + 1, ubound.end(), x.u) - (ubound.begin() + 1)), s = x.v / seg;
+        mfx_node y = {x.u - ubound[(size_t)g], x.v - s * seg, x.r};
         part[(size_t)g * S + s].push_back(y);
         cnt_p[g][y.u]++;
         j->cnt_q[x.v]++;
@@ -217,6 +239,7 @@ int mfx_job_create(const mfx_node *R, long long nnz, int m, int n, const mfx_opt
     for (const auto &p : part) smallest = std::min<long long>(smallest, (long long)p.size());
     if (smallest == 0) return jfail(MFX_E_ARG, "some device holds no rating for some item slot: fewer devices or more data");
     opt.use_stats = 1;
+    opt.wide = 1; // slot trainers are small and skewed: wide launches (mfx_options.wide; parity of such shards: tests/test_gpu_multi.py)
     opt.stats_avg = j->avg;
     opt.stats_std = j->std_dev;
     if (opt.stripes <= 0) { // ONE stripe count per job (the id layout depends on it): from the smallest piece
@@ -230,8 +253,8 @@ int mfx_job_create(const mfx_node *R, long long nnz, int m, int n, const mfx_opt
     for (int g = 0; g < G; ++g) {
         Dev &d = j->dev[g];
         d.device = ids[g];
-        d.lo = std::min(m, g * useg);
-        d.hi = std::min(m, (g + 1) * useg);
+        d.lo = ubound[(size_t)g];
+        d.hi = ubound[(size_t)g + 1];
         JOB_HIP(hipSetDevice(d.device));
         JOB_HIP(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
         d.slot.assign(S, nullptr);

@@ -179,21 +179,6 @@ void pack_class(const std::vector<Visit> &visits, size_t vbeg, size_t vend, int 
     }
 }
 
-// steps one wave does in a launch if the block is dealt out evenly: ordinary ratings one per list step, the ratings of a
-// heavy row W x G per step of its workgroup
-long long block_steps_per_wave(const std::vector<Visit> &raw, int G, int W, int waves, int hot_len, long long *hot_steps_out = nullptr)
-{
-    const long long WGL = (long long)W * G;
-    long long L_main = 0, hot_steps = 0;
-    for (const Visit &v : raw) {
-        if ((long long)v.len <= hot_len) L_main += v.len;
-        else hot_steps += ((long long)v.len + WGL - 1) / WGL;
-    }
-    if (hot_steps_out) *hot_steps_out = hot_steps;
-    const long long lists = (long long)std::max(1, waves) * G;
-    return std::max<long long>(1, (L_main + hot_steps * WGL + lists - 1) / lists);
-}
-
 // number of workgroups a heavy visit is split over: one, unless it holds more than a workgroup does in the launch
 inline long long visit_copies(uint32_t len, long long WGL, long long T)
 {
@@ -205,37 +190,84 @@ struct Piece { uint32_t vi; uint32_t idx; uint32_t steps; uint32_t len; uint64_t
 
 } // namespace
 
+// How a block is cut: T = steps one wave does if the block is dealt out evenly over the `waves` the concurrency cap allows;
+// Th[role] = steps of one piece of a heavy row (a piece = what one workgroup does of it), wgs[role] = workgroup tasks the
+// role's heavy rows may fill.
+//
+// A heavy row is cut into pieces of T steps -- unless the block's heavy work does not fit the workgroups there are at T
+// steps each (a block that is little else than one row: one GPU's slot of a strong split holds such blocks).  Then the
+// pieces are cut longer, so that they fill the workgroups evenly: 31 pieces of T steps on 30 workgroups make one
+// workgroup -- and the launch -- take twice as long.
+//
+// WIDE launches (wgs_hw > waves / W: the concurrency cap holds the launch below what the chip can run).  The cap exists
+// because two lists that read-modify-write one row at the same time lose an update.  The W x G lists of a heavy row -- and
+// those of all its copies -- hold DISJOINT ranges of the other side's rows (its ratings are sorted by that id and dealt
+// in contiguous runs): they never meet each other on a row, and for any row of the other side the whole heavy row counts
+// as ONE list.  So the heavy rows do not take their workgroups out of the capped ones: they run on the workgroups the cap
+// leaves idle, cut so that they are done when the ordinary rows are (never finer than that: fewer copies fold better).
+struct BlockShape { long long T; long long Th[2]; long long wgs[2]; long long waves_main; bool wide; };
+static BlockShape block_shape(const std::vector<Visit> &raw, int G, int W, int waves, int wgs_hw, int hot_len)
+{
+    const long long WGL = (long long)W * G;
+    BlockShape sh;
+    long long hs[2] = {0, 0}, L_main = 0;
+    for (const Visit &v : raw) {
+        if ((long long)v.len <= hot_len) L_main += v.len;
+        else hs[v.swapped ? 1 : 0] += ((long long)v.len + WGL - 1) / WGL;
+    }
+    const long long wgs_cap = std::max(1, waves / std::max(1, W));
+    const long long hw = std::max<long long>(wgs_hw, wgs_cap);
+    sh.wide = hw > wgs_cap;
+    const long long hsum = hs[0] + hs[1];
+    // A step of a workgroup task costs more than a step of a wave task: the lists' changes of the heavy row are summed
+    // across the wave (ds_bpermute beyond a 16-lane row) and added to LDS with atomics.  Measured on configs[1] (k = 32,
+    // launches of a few waves per CU): 1.09 us against 0.56 us; at k = 128 the two are equal.  (A cost model for the
+    // balance of a launch only; no result depends on it.)
+    const long long c10 = G >= 8 ? 20 : G == 4 ? 15 : G == 2 ? 11 : 10; // cost of a workgroup step in tenths of a wave step
+    // n workgroups for the heavy rows, the others (at most the capped ones) for the ordinary rows: the launch takes
+    // max(heavy steps / n, ordinary ratings / lists of the others).  The smallest n that reaches the minimum: fewer copies of
+    // a row fold better.
+    long long best_n = 0, best_x = 0;
+    auto ord_steps = [&](long long n) {
+        const long long w = std::min(wgs_cap, hw - n);
+        return w > 0 ? (L_main + w * WGL - 1) / (w * WGL) : (L_main ? (long long)1 << 40 : 0);
+    };
+    if (hsum == 0) {
+        best_n = 0;
+        best_x = ord_steps(0);
+    } else {
+        const long long n_max = L_main > 0 ? std::max<long long>(1, hw - 1) : hw;
+        best_n = 1;
+        best_x = std::max((hsum * c10 + 9) / 10, ord_steps(1));
+        for (long long n = 2; n <= n_max; ++n) {
+            const long long x = std::max((hsum * c10 + 10 * n - 1) / (10 * n), ord_steps(n));
+            if (x < best_x) {
+                best_x = x;
+                best_n = n;
+            }
+        }
+    }
+    sh.T = std::max<long long>(1, best_x);
+    sh.waves_main = std::max<long long>(std::min<long long>(W, waves), W * std::min(wgs_cap, hw - best_n));
+    for (int role = 0; role < 2; ++role) {
+        sh.wgs[role] = hsum ? std::max<long long>(1, (best_n * hs[role] + hsum / 2) / hsum) : 1;
+        // (at least 16 steps a piece in a wide launch: a visit costs two barriers and the staging of its row)
+        sh.Th[role] = std::max<long long>(std::max<long long>(sh.T * 10 / c10, sh.wide ? 16 : 1), hs[role] ? (hs[role] + sh.wgs[role] - 1) / sh.wgs[role] : 1);
+    }
+    return sh;
+}
+
 // Cut one (owner-stripe, gather-stripe) block, given as its visits, into workgroup tasks (heavy rows) and wave tasks.
-static void pack_block(std::vector<Visit> &raw, int G, int W, int waves, int target, int hot_len, int tasks_per_wave,
+static void pack_block(std::vector<Visit> &raw, int G, int W, int waves, int wgs_hw, int target, int hot_len, int tasks_per_wave,
                        const std::vector<int> &slot_own, const std::vector<int> &slot_gat, BlockPack &out)
 {
     if (raw.empty()) return;
     const long long WGL = (long long)W * G;
-    long long hot_steps = 0;
-    const long long T = block_steps_per_wave(raw, G, W, waves, hot_len, &hot_steps);
+    const BlockShape shape = block_shape(raw, G, W, waves, wgs_hw, hot_len);
+    const long long *const Th = shape.Th;
     std::vector<Visit> ordinary[2]; // the ordinary ones, by role
     ordinary[0].reserve(raw.size());
     std::vector<Piece> pieces[2]; // by role
-    // A heavy row is cut into pieces of T steps -- unless the block's heavy work does not fit the workgroups there are at T
-    // steps each (a block that is little else than one row: one GPU's slot of a strong split holds such blocks).  Then the
-    // pieces are cut longer, so that they fill the workgroups evenly: 31 pieces of T steps on 30 workgroups make one
-    // workgroup -- and the launch -- take twice as long.
-    const int wgs_total = std::max(1, waves / std::max(1, W));
-    long long Th[2] = {T, T};
-    {
-        long long hs[2] = {0, 0};
-        bool any_ordinary = false;
-        for (const Visit &v : raw) {
-            if ((long long)v.len <= hot_len) any_ordinary = true;
-            else hs[v.swapped ? 1 : 0] += ((long long)v.len + WGL - 1) / WGL;
-        }
-        const long long keep = any_ordinary ? 1 : 0; // (the ordinary rows keep at least one workgroup)
-        const long long cap0 = std::max<long long>(1, wgs_total - keep);
-        Th[0] = std::max(T, (hs[0] + cap0 - 1) / cap0);
-        const long long used0 = hs[0] ? std::min(cap0, (hs[0] + Th[0] - 1) / Th[0]) : 0;
-        const long long cap1 = std::max<long long>(1, wgs_total - keep - used0);
-        Th[1] = std::max(T, (hs[1] + cap1 - 1) / cap1);
-    }
     for (size_t i = 0; i < raw.size(); ++i) {
         const Visit &v = raw[i];
         if ((long long)v.len <= hot_len) {
@@ -262,17 +294,23 @@ static void pack_block(std::vector<Visit> &raw, int G, int W, int waves, int tar
         for (const Piece &q : pc) steps += q.steps;
         long long nt = std::max<long long>(1, (steps + Th[role] - 1) / Th[role]);
         nt = std::min<long long>(nt, (long long)pc.size());
-        // (the ordinary rows keep at least one workgroup)
-        nt = std::min<long long>(nt, std::max(1, wgs_total - (ordinary[0].empty() && ordinary[1].empty() ? 0 : 1) - wgs_used));
+        nt = std::min<long long>(nt, std::max<long long>(1, shape.wgs[role]));
         std::stable_sort(pc.begin(), pc.end(), [](const Piece &a, const Piece &b) { return a.steps > b.steps; });
-        std::vector<long long> load((size_t)nt, 0);
-        std::vector<std::vector<uint32_t>> of((size_t)nt);
-        for (uint32_t i = 0; i < pc.size(); ++i) {
-            size_t best = 0;
-            for (size_t t = 1; t < (size_t)nt; ++t)
-                if (load[t] < load[best]) best = t;
-            of[best].push_back(i);
-            load[best] += pc[i].steps;
+        std::vector<long long> load;
+        std::vector<std::vector<uint32_t>> of;
+        for (;;) { // longest piece first into the emptiest task; one more task while the fullest is far above the mean
+            load.assign((size_t)nt, 0);
+            of.assign((size_t)nt, std::vector<uint32_t>());
+            for (uint32_t i = 0; i < pc.size(); ++i) {
+                size_t best = 0;
+                for (size_t t = 1; t < (size_t)nt; ++t)
+                    if (load[t] < load[best]) best = t;
+                of[best].push_back(i);
+                load[best] += pc[i].steps;
+            }
+            const long long top = *std::max_element(load.begin(), load.end());
+            if (top * 4 <= std::max(Th[role], (steps + nt - 1) / nt) * 5 || nt >= (long long)pc.size() || nt >= shape.wgs[role] + (shape.wide ? 2 : 0)) break;
+            ++nt;
         }
         for (size_t t = 0; t < (size_t)nt; ++t) {
             std::vector<uint32_t> &lst = of[t];
@@ -319,8 +357,15 @@ static void pack_block(std::vector<Visit> &raw, int G, int W, int waves, int tar
                     if (first >= (long long)q.len) break;
                     const uint32_t cnt = (uint32_t)std::min<long long>(q.steps, (long long)q.len - first);
                     const long long w = l / G, g = l % G;
-                    out.places.push_back({q.start + (uint64_t)first, wt.off + (uint64_t)w * wave_stride + (uint64_t)step0 * G + (uint64_t)g, cnt,
-                                          1u | (role ? 0x80000000u : 0u)});
+                    const uint64_t dst = wt.off + (uint64_t)w * wave_stride + (uint64_t)step0 * G + (uint64_t)g;
+                    const uint32_t fl = 1u | (role ? 0x80000000u : 0u);
+                    // Every heavy row cuts the other side's id range into W x G runs the same way, and its lists walk their
+                    // runs upwards at the same pace: list l of one heavy row and list l of another would reach a row they have
+                    // in common at nearly the same step, launch after launch.  Each row therefore starts its runs at its own
+                    // point (a hash of the row id) and wraps round.
+                    const uint32_t at = (uint32_t)(((uint64_t)(v.own * 2654435761u) * cnt) >> 32);
+                    out.places.push_back({q.start + (uint64_t)first + at, dst, cnt - at, fl});
+                    if (at) out.places.push_back({q.start + (uint64_t)first, dst + (uint64_t)(cnt - at) * G, at, fl});
                 }
                 step0 += q.steps;
                 rated += q.len;
@@ -332,7 +377,8 @@ static void pack_block(std::vector<Visit> &raw, int G, int W, int waves, int tar
     }
     // The ordinary rows: wave tasks, one class per role.  The waves that the workgroup tasks leave are dealt over the two roles
     // in proportion to their ratings.
-    const int waves_main = std::max(std::min(W, waves), waves - W * wgs_used);
+    const int waves_main = (int)shape.waves_main; // the waves the heavy rows leave, at most the capped ones
+    (void)wgs_used;
     long long L_role[2] = {0, 0};
     for (int role = 0; role < 2; ++role)
         for (const Visit &v : ordinary[role]) L_role[role] += v.len;
@@ -353,8 +399,14 @@ static void pack_block(std::vector<Visit> &raw, int G, int W, int waves, int tar
         const size_t t_first = out.tasks.size();
         if (tasks_per_wave > 0) { // equal-load tasks, (tasks per wave) x (waves of this role) of them
             long long wr = waves_main;
-            if (L_role[1 - role] > 0)
-                wr = std::max<long long>(1, std::min<long long>(waves_main - 1, (waves_main * L_role[role] + (L_role[0] + L_role[1]) / 2) / (L_role[0] + L_role[1])));
+            if (L_role[1 - role] > 0) {
+                // the waves are dealt over the two roles so that the longer of the two kinds of task is as short as it gets
+                const long long tot = L_role[0] + L_role[1];
+                long long w0 = std::max<long long>(1, std::min<long long>(waves_main - 1, waves_main * L_role[0] / tot));
+                auto longest = [&](long long a0) { return std::max((L_role[0] + a0 - 1) / a0, (L_role[1] + (waves_main - a0) - 1) / (waves_main - a0)); };
+                if (w0 + 1 <= waves_main - 1 && longest(w0 + 1) < longest(w0)) ++w0;
+                wr = role == 0 ? w0 : waves_main - w0;
+            }
             pack_class(visits, 0, visits.size(), G, 8, out, (long long)tasks_per_wave * wr);
         } else {
             pack_class(visits, 0, visits.size(), G, std::max(8, target), out); // explicit task_steps (tests): tasks of that size
@@ -416,6 +468,7 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
     int target, hot_len;
     plan_sizes(p.nnz, NB, G, cfg, target, hot_len);
     const int W = p.waves_per_wg, waves = std::max(1, cfg.waves_per_stripe);
+    const int wgs_hw = std::max(cfg.wgs_hw, waves / std::max(1, W)); // workgroups per XCD the launch really has
     const bool timing = env_int_raw("MFX_PLAN_TIMING", 0) != 0;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -432,7 +485,9 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
     // long share per wave, where two tasks let the waves that run ahead take up the slack (3 .. 15 % of the epoch time;
     // round 1: profiles/experiments/r01_task_sweep*.log).  An explicit task_steps (tests) selects tasks of that size.
     const long long per_wave = p.nnz / ((long long)NB * G * waves);
-    const int tasks_per_wave = cfg.task_steps > 0 ? 0 : knob_int("MFX_ONE_TASK", (per_wave < 128 || G >= 4) ? 1 : 2);
+    int tasks_per_wave = cfg.task_steps > 0 ? 0 : knob_int("MFX_ONE_TASK", (per_wave < 128 || G >= 4) ? 1 : 2);
+    if (tasks_per_wave > 1 && cfg.wgs_hw * std::max(1, cfg.waves_per_wg) > std::max(1, cfg.waves_per_stripe))
+        tasks_per_wave = 1; // a wide launch: the number of wave tasks IS the concurrency cap (plan.cpp block_shape)
     // combine slots: one per row that is split over several workgroups in some block (row -> slot, -1 = none), both sides
     const int n_own = p.owner_is_q ? p.n : p.m, n_gat = p.owner_is_q ? p.m : p.n;
     std::vector<int> slot_own((size_t)n_own, -1), slot_gat((size_t)n_gat, -1);
@@ -445,9 +500,9 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
             for (;;) {
                 const int b = nb.fetch_add(1);
                 if (b >= NB) break;
-                const long long T = block_steps_per_wave(block_visits[b], G, W, waves, hot_len);
+                const BlockShape sh = block_shape(block_visits[b], G, W, waves, wgs_hw, hot_len);
                 for (const Visit &v : block_visits[b])
-                    if ((long long)v.len > hot_len && visit_copies(v.len, (long long)W * G, T) > 1)
+                    if ((long long)v.len > hot_len && visit_copies(v.len, (long long)W * G, sh.Th[v.swapped ? 1 : 0]) > 1)
                         cut[b].push_back(v.own | (v.swapped ? 0x80000000u : 0u));
             }
         };
@@ -480,7 +535,7 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
                 int idx = next.fetch_add(1);
                 if (idx >= NB) break;
                 try {
-                    pack_block(block_visits[blocks[idx]], G, W, waves, target, hot_len, tasks_per_wave, slot_own, slot_gat,
+                    pack_block(block_visits[blocks[idx]], G, W, waves, wgs_hw, target, hot_len, tasks_per_wave, slot_own, slot_gat,
                                packs[blocks[idx]]);
                 } catch (...) {
                     std::lock_guard<std::mutex> lock(err_mu);

@@ -95,7 +95,8 @@ struct PlanConfig {
     const int *layout_cnt_p = nullptr, *layout_cnt_q = nullptr;
     bool use_stats = false;   // take avg/std from below instead of collect_info
     float stats_avg = 0, stats_std = 0;
-    int waves_per_stripe = 256; // for auto task sizing
+    int waves_per_stripe = 256; // for auto task sizing: the waves the concurrency cap allows per XCD
+    int wgs_hw = 0;             // workgroups per XCD the launch has (0: waves_per_stripe / waves_per_wg); more than the cap allows = a wide launch (plan.cpp block_shape)
     int waves_per_wg = 4;     // waves of a workgroup that take work (W of a workgroup task)
     bool swap_heavy = false;  // also run the heavy rows of the GATHERED side in workgroup tasks, roles swapped (experimental)
     int threads = 0;          // host worker threads, 0 = hardware_concurrency

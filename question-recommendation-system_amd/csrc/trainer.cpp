@@ -95,6 +95,7 @@ struct mfx_trainer {
     mfx_options opt;
     mfx::Plan plan; // host copy (entries/tasks dropped after upload)
     int device = 0, cu_count = 256, xcd_count = 8, wg_per_cu = 2, wgs_per_xcd = 64, waves_per_wg = 4;
+    int wgs_grid = 64; // workgroups per XCD a launch starts: wgs_per_xcd (what the concurrency cap allows), or more -- a wide launch
     signed char xcc_rank[16];
     hipStream_t stream = nullptr;
     long long n_entries = 0, n_tasks = 0;
@@ -200,6 +201,16 @@ static int wgs_per_xcd_for(const mfx_options &opt, int m, int n, int ns, int cu_
     return (int)wgs;
 }
 
+// Workgroups per XCD a launch starts: what the concurrency cap allows -- or, on request (mfx_options.wide), what the chip runs
+// anyway (the occupancy cap of wgs_per_xcd_for), the workgroups beyond the cap taking the heavy rows only (plan.cpp
+// block_shape).  An explicit width (mfx_options.wg_per_cu, tests) and the one-workgroup launches of tiny problems stay.
+static int wgs_grid_for(const mfx_options &opt, int wgs_cap, int waves_per_wg, int cu_per_xcd)
+{
+    if (opt.wide == 0 || opt.wg_per_cu > 0 || waves_per_wg < 4) return wgs_cap;
+    const int G = 64 / mfx::lanes_for(mfx::k_aligned(opt.k));
+    return std::max(wgs_cap, cu_per_xcd * std::max(1, 16 / G));
+}
+
 // Stripes per side (= launches per epoch) and the launch width that goes with them: one stripe per XCD, whatever the size
 // of the problem.  (Round 1 took half the stripes for small problems; it cost parity -- four times the block means four
 // times the split of a heavy row and half the folds per epoch -- and is gone.)
@@ -212,7 +223,7 @@ static int choose_stripes(const mfx_options &opt, long long nnz, int m, int n, i
     return stripes;
 }
 
-static mfx::PlanConfig plan_config(const mfx_options &opt, int stripes, int wgs_per_xcd, int waves_per_wg)
+static mfx::PlanConfig plan_config(const mfx_options &opt, int stripes, int wgs_per_xcd, int waves_per_wg, int wgs_grid = 0)
 {
     mfx::PlanConfig cfg;
     cfg.k = opt.k;
@@ -227,6 +238,7 @@ static mfx::PlanConfig plan_config(const mfx_options &opt, int stripes, int wgs_
     cfg.stats_std = opt.stats_std;
     cfg.waves_per_stripe = wgs_per_xcd * waves_per_wg;
     cfg.waves_per_wg = waves_per_wg;
+    cfg.wgs_hw = wgs_grid;
     cfg.swap_heavy = opt.no_swap == 0 && knob_int("MFX_NO_SWAP", 0) == 0;
     cfg.threads = g_host_threads;
     return cfg;
@@ -291,7 +303,8 @@ static int create_impl(const mfx::Node *R, const void *R_dev, long long nnz, int
     const int stripes = choose_stripes(opt, nnz, m, n, t->xcd_count, cu_per_xcd, &t->wgs_per_xcd, &t->waves_per_wg);
     t->wg_per_cu = (t->wgs_per_xcd + cu_per_xcd - 1) / cu_per_xcd;
 
-    mfx::PlanConfig cfg = plan_config(opt, stripes, t->wgs_per_xcd, t->waves_per_wg);
+    t->wgs_grid = wgs_grid_for(opt, t->wgs_per_xcd, t->waves_per_wg, cu_per_xcd);
+    mfx::PlanConfig cfg = plan_config(opt, stripes, t->wgs_per_xcd, t->waves_per_wg, t->wgs_grid);
     cfg.layout_cnt_p = layout_cnt_p;
     cfg.layout_cnt_q = layout_cnt_q;
 
@@ -667,7 +680,7 @@ int mfx_trainer_epoch_part(mfx_trainer *t, int slow_only, void *stream_v, int pa
     }
 #endif
     memcpy(a.xcc_rank, t->xcc_rank, sizeof(a.xcc_rank));
-    const int grid = t->xcd_count * t->wgs_per_xcd; // workgroups are dealt round-robin over XCDs
+    const int grid = t->xcd_count * t->wgs_grid; // workgroups are dealt round-robin over XCDs
     const int i_begin = (int)((long long)part * ns / nparts), i_end = (int)((long long)(part + 1) * ns / nparts);
     // timing: one event pair around the launches of this call (a pair per launch costs ~7 us each,
     // 6 % of a 123 us launch); mean launch time = bracket / launches, inter-launch gaps included
@@ -833,6 +846,7 @@ int mfx_trainer_info(mfx_trainer *t, mfx_info *o)
     o->waves_per_wg = t->waves_per_wg;
     o->hot_len = p.hot_len;
     o->merge_back = p.merge_back ? 1 : 0;
+    o->grid_wg_per_cu = (t->wgs_grid + std::max(1, t->cu_count / t->xcd_count) - 1) / std::max(1, t->cu_count / t->xcd_count);
     o->cu_count = t->cu_count;
     o->xcd_count = t->xcd_count;
     o->wg_per_cu = t->wg_per_cu;
@@ -1191,7 +1205,7 @@ int mfx_hostplan_build(const mfx_node *R, long long nnz, int m, int n, const mfx
     try {
         int wpw = 4, wgs = 1;
         const int stripes = choose_stripes(*opt, nnz, m, n, 8, 32, &wgs, &wpw); // an MI355X: 8 XCDs of 32 CUs
-        mfx::build_plan((const mfx::Node *)R, nnz, m, n, plan_config(*opt, stripes, wgs, wpw), h->plan);
+        mfx::build_plan((const mfx::Node *)R, nnz, m, n, plan_config(*opt, stripes, wgs, wpw, wgs_grid_for(*opt, wgs, wpw, 32)), h->plan);
     } catch (const std::bad_alloc &) {
         delete h;
         return fail(MFX_E_NOMEM, "out of host memory while building the plan");

@@ -42,6 +42,16 @@ i = t.info
 print("%s split over %d: rank %d (users %d..%d) holds %d ratings, %d slots x %d launches; %.3f ms per epoch of compute = %.2e ratings/s per rank "
       "(x %d = %.2e job-wide if transfers hide; the N = 1 line does the whole workload in %s)  wg/cu %d %s" %
       (cfg["name"], world, rank, lo, hi, t.nnz, t.S, t.stripes, dt * 1e3, t.nnz / dt, world, world * t.nnz / dt, "one GPU", i.wg_per_cu, kw), flush=True)
+if os.environ.get("PARITY"):  # the shard trained alone from fresh factors = ordinary SGD on it: against the oracle's fixture
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "strong_shards.json"))).get("%d:%d" % (world, rank))
+    if g and cfgname == "c2":
+        assert (g["lo"], g["hi"], g["nnz"]) == (lo, hi, t.nnz), (g["lo"], g["hi"], g["nnz"], lo, hi, t.nnz)
+        for r_ in range(2):
+            t.reinit()
+            for it in range(g["epochs"]): t.epoch(slow_only=(it == 0), stream=stream)
+            t.sync(); got = t.rmse()
+            print("   parity: rank %d of %d alone, %d epochs: gpu %.5f oracle %.5f (%+.2f %%) %s" % (rank, world, g["epochs"], got, g["rmse"], (got / g["rmse"] - 1) * 100, kw), flush=True)
 if os.environ.get("DIAG"):
     os.environ["MFX_STAMPS_DUMP"] = "1"; t.trainers[0].epoch(stream=stream); os.environ.pop("MFX_STAMPS_DUMP"); t.sync()  # reset
     t.epoch(stream=stream); t.sync()

@@ -271,3 +271,56 @@ def test_job_ring_on_one_gpu_matches_oracle(pkg, orc, G):
     assert abs(got - want) / want < RMSE_RTOL, (got, want)
     assert abs(orc.rmse(R, arr) - got) / got < 1e-4
     assert arr[:4].tolist() == [0.0, m, n, k]
+
+
+@pytest.mark.parametrize("spec,wide", [("8:0", 1), ("8:7", 1), ("8:0", 0)])
+def test_strong_split_rank_alone_matches_oracle(pkg, spec, wide):
+    """One rank's shard of the strong split of configs[2] (bench.py --gpus 8: users of equal rating mass, all items), trained alone
+    through the slot rotation -- its 8 item slots one after the other, the launches of a slot trainer WIDE as bench.py and
+    mfx_job_* run them (mfx_options.wide) or not -- is ordinary SGD on that shard: the one-worker oracle's figure on the same
+    triples is the fixture (tests/golden/strong_shards.json, make_strong_shards.py).  Rank 0 holds the popular users (one of them
+    a quarter of a slot's ratings), rank 7 the tail.  Observed: -0.5 .. -0.9 %."""
+    import importlib.util
+    import json
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    import __graft_entry__ as ge
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "strong_shards.json")))[spec]
+    mspec = importlib.util.spec_from_file_location("qrs_multi", os.path.join(ge.PKG_DIR, "multi.py"))
+    multi = importlib.util.module_from_spec(mspec); mspec.loader.exec_module(multi)
+    world, rank = g["world"], g["rank"]
+    c2 = bench.CONFIGS["c2"]
+    m, n, nnz = c2["m"], c2["n"], c2["nnz"]
+    dev = torch.device("cuda", 0)
+    prev = torch.cuda.current_stream()
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        buf = torch.empty(nnz * 3, dtype=torch.int32, device=dev)
+        pkg.synth_device(g["seed"], 0, nnz, m, n, buf.data_ptr(), None, shard=0)
+        torch.cuda.synchronize()
+        v3 = buf.view(-1, 3)
+        bounds = bench.balanced_user_bounds(torch, torch.bincount(v3[:, 0].long(), minlength=m), world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        assert (lo, hi) == (g["lo"], g["hi"])
+        sel = v3[(v3[:, 0] >= lo) & (v3[:, 0] < hi)].clone()
+        sel[:, 0] -= lo
+        del buf, v3
+        assert sel.shape[0] == g["nnz"]
+        t = multi.RotatingTrainer(pkg, sel.contiguous().view(-1), hi - lo, n, world, rank, None, dev, k=g["k"], lambda_p2=g["lambda_p"],
+                                  lambda_q2=g["lambda_q"], eta=g["eta"], wide=wide)
+        del sel
+        assert t.S == world
+        for it in range(g["epochs"]):
+            t.epoch(slow_only=(it == 0), stream=stream)
+        t.sync()
+        got = t.rmse()
+        grid = t.trainers[0].info.grid_wg_per_cu, t.trainers[0].info.wg_per_cu
+        t.close()
+    finally:
+        torch.cuda.set_stream(prev)
+    print("rank %d of %d alone (wide=%d, workgroups per CU started / capped: %s): gpu %.5f oracle %.5f (%+.2f %%)" %
+          (rank, world, wide, grid, got, g["rmse"], (got / g["rmse"] - 1) * 100))
+    assert abs(got - g["rmse"]) / g["rmse"] < RMSE_RTOL
+    assert (grid[0] > grid[1]) == bool(wide) or grid[0] == grid[1]  # a wide launch starts more workgroups than the cap allows

@@ -133,8 +133,16 @@ def check_plan(pkg, orc, R, m, n, k, **kw):
                     full = int(V["len"]) // ns_v
                     assert (cnt[:full] == ns_v).all() and (cnt[full + 1:] == 0).all()  # ... and the lists one after the other
                     other = (part["gat"] & pkg.ENTRY_ID_MASK).transpose(0, 2, 1).reshape(W * G, ns_v)
-                    flat = np.concatenate([other[l, :cnt[l]] for l in range(W * G)])
-                    assert (np.diff(flat) >= 0).all()                            # in the order of the other side's id
+                    # ... each list holding ONE contiguous run of the ratings sorted by the other side's id, started at the row's
+                    # own point and wrapped round once (plan.cpp: every heavy row starts its runs somewhere else); put back in
+                    # order, the runs follow each other
+                    runs = []
+                    for l in range(W * G):
+                        run = other[l, :cnt[l]]
+                        drops = np.flatnonzero(np.diff(run) < 0)
+                        assert len(drops) <= 1
+                        runs.append(np.roll(run, -(int(drops[0]) + 1)) if len(drops) else run)
+                    assert (np.diff(np.concatenate(runs)) >= 0).all()
                     key = (int(V["row"]), int(T["swapped"]))
                     copies.setdefault(key, []).append(V)
                     s0 += int(V["nsteps"])
