@@ -1,13 +1,9 @@
-# round 3: same-box A/B of the committed library (lib_head) against the working tree (default plan and wide=1)
+# round 3, final code: every full-size fixture and every held-out law, two single runs each (profiles/experiments/r03_fixtures_every_run.log)
 set -o pipefail
-Q=gpurun_out/r3_wide_ab.log; : > $Q
-H=/root/repo/question-recommendation-system_amd/lib_head/libmf.so
-run() { # label, env lib, opts
-  echo "== $1" >> $Q
-  for c in "c1 12" "c1 20" "c2s 12" "c3shard 8" "c2 12" "c4shard 4"; do MFX_LIB=$2 timeout -k 10 300 python scripts/gpu_quick.py $c 1 $3 2>&1 | grep -v amdgpu.ids >> $Q || exit 1; done
-  MFX_LIB=$2 timeout -k 10 400 python scripts/gpu_heldout_quick.py zipf11 rect zipf11_k64 eta02_lam001 $3 2>&1 | grep -v amdgpu.ids >> $Q || exit 1
-}
-run "HEAD library" $H ""
-run "working tree, default" "" ""
-run "working tree, wide=1" "" "wide=1"
+Q=gpurun_out/r3_final_parity.log; : > $Q
+for c in "c1 12" "c1 20" "c2 8" "c2 12" "c2 20" "c2s 12" "c3shard 8" "c4shard 4"; do timeout -k 10 300 python scripts/gpu_quick.py $c 2 2>&1 | grep -v amdgpu.ids >> $Q || exit 1; done
+timeout -k 10 600 python scripts/gpu_heldout_quick.py uniform zipf11 zipf11dup rect eta005_lam001 eta005_lam05 eta02_lam001 eta02_lam05 zipf11_k64 2>&1 | grep -v amdgpu.ids >> $Q || exit 1
+echo "== wide=1" >> $Q
+for c in "c1 12" "c1 20"; do timeout -k 10 300 python scripts/gpu_quick.py $c 2 wide=1 2>&1 | grep -v amdgpu.ids >> $Q || exit 1; done
+timeout -k 10 600 python scripts/gpu_heldout_quick.py uniform zipf11 rect eta005_lam001 eta02_lam001 zipf11_k64 wide=1 2>&1 | grep -v amdgpu.ids >> $Q || exit 1
 cat $Q
