@@ -868,6 +868,152 @@ __global__ __launch_bounds__(256) MFX_OCC void sgd_round(RoundArgs a)
     }
 }
 
+// ---- rows wider than one float4 per lane (256 < k_a <= 1024) --------------------------------------------------------
+// The same update on the same plan, one rating per wavefront step (G = 1) and V float4 per lane (factors (v*64 + lane)*4 ..
+// of chunk v: a chunk is one contiguous kilobyte across the wave).  The plan of such a problem has wave tasks only -- a heavy
+// row is one long list, the roles are not swapped (plan.cpp: PlanConfig::wide_rows) -- and this kernel is the step loop
+// without its latency hiding (no entry ring, no hand-over under the last steps): correct first, the reference's k in use
+// is 8 .. 128.  Same arithmetic as sgd_round: gradients from the OLD values, accumulator slots [0,8) / [8,k_a), rk = 1/8 for
+// both (quirk Q1), v_rsq_f32, epoch 0 moves the first eight factors only.
+template <int V, bool SLOW>
+__global__ __launch_bounds__(256) void sgd_round_wide(RoundArgs a)
+{
+    constexpr unsigned NONE = 0xFFFFFFFFu, IDMASK = 0x3FFFFFFFu;
+    const int lane = threadIdx.x & 63;
+    const int ka = a.ka;
+    const float lam_o = a.lambda_own, lam_g = a.lambda_gat, eta = a.eta;
+    const float rk0 = 0.125f, rk1 = a.rk1;
+    const f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int rank = a.xcc_rank[xcc_id() & 15];
+    const bool wave_on = (int)(threadIdx.x >> 6) < a.active_waves;
+    double lsum = 0.0;
+    bool ok[V], s1[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int d0 = (v * 64 + lane) * 4;
+        ok[v] = d0 < ka;
+        s1[v] = d0 >= 8;
+    }
+    if (rank >= 0 && wave_on)
+        for (int slot = rank; slot < a.ns; slot += a.n_xcc) {
+            const long long tbeg = a.slot_task_ptr[slot];
+            const int ntask = (int)(a.slot_task_ptr[slot + 1] - tbeg);
+            for (;;) {
+                int c = 0;
+                if (lane == 0) c = atomicAdd(&a.slot_cursor[slot], 1);
+                c = __builtin_amdgcn_readfirstlane(c);
+                if (c >= ntask) break;
+                const TaskDescD td = a.tasks[tbeg + c];
+                const EntryD *const ebase = a.entries + td.off;
+                const int nsteps = (int)td.nsteps;
+                unsigned cur = NONE;
+                f4 o[V];
+#pragma unroll
+                for (int v = 0; v < V; ++v) o[v] = zero4;
+                float og0 = 1.0f, og1 = 1.0f, tsum = 0.0f;
+                auto write_back = [&]() {
+#pragma unroll
+                    for (int v = 0; v < V; ++v)
+                        if (ok[v]) *(f4 *)(a.own_rows + (size_t)cur * ka + (v * 64 + lane) * 4) = o[v];
+                    if (lane == 0) *(f2 *)(a.own_acc + (size_t)cur * 2) = f2{og0, og1};
+                };
+                for (int step = 0; step < nsteps; ++step) {
+                    const EntryD e = ebase[step];
+                    if (e.gat < 0) continue; // padding
+                    const unsigned id = e.own & IDMASK;
+                    if (id != cur) { // a visit starts: the row of the one before goes back
+                        if (cur != NONE) write_back();
+#pragma unroll
+                        for (int v = 0; v < V; ++v) o[v] = ok[v] ? ld_row(a.own_rows + (size_t)id * ka + (v * 64 + lane) * 4) : zero4;
+                        const f2 og = ld_acc(a.own_acc + (size_t)id * 2);
+                        og0 = og.x;
+                        og1 = og.y;
+                        cur = id;
+                    }
+                    float *const gp = a.gat_rows + (size_t)(e.gat & 0x3FFFFFFF) * ka;
+                    float *const gap = a.gat_acc + (size_t)(e.gat & 0x3FFFFFFF) * 2;
+                    f4 g[V];
+                    float z = 0.0f;
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        g[v] = ok[v] ? ld_row(gp + (v * 64 + lane) * 4) : zero4;
+                        z += o[v].x * g[v].x + o[v].y * g[v].y + o[v].z * g[v].z + o[v].w * g[v].w;
+                    }
+                    f2 gg = ld_acc(gap);
+                    z = group_sum<64>(z);
+                    const float err = e.r - z;
+                    tsum += err * err;
+                    const float eo0 = eta * __builtin_amdgcn_rsqf(og0), eo1 = eta * __builtin_amdgcn_rsqf(og1);
+                    const float eg0 = eta * __builtin_amdgcn_rsqf(gg.x), eg1 = eta * __builtin_amdgcn_rsqf(gg.y);
+                    float so0 = 0.0f, so1 = 0.0f, sg0 = 0.0f, sg1 = 0.0f;
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        if (!ok[v] || (SLOW && s1[v])) continue;
+                        const f4 go = lam_o * o[v] - err * g[v], gq = lam_g * g[v] - err * o[v];
+                        const float so = go.x * go.x + go.y * go.y + go.z * go.z + go.w * go.w;
+                        const float sg = gq.x * gq.x + gq.y * gq.y + gq.z * gq.z + gq.w * gq.w;
+                        if (s1[v]) {
+                            so1 += so;
+                            sg1 += sg;
+                            o[v] -= eo1 * go;
+                            g[v] -= eg1 * gq;
+                        } else {
+                            so0 += so;
+                            sg0 += sg;
+                            o[v] -= eo0 * go;
+                            g[v] -= eg0 * gq;
+                        }
+                    }
+#pragma unroll
+                    for (int v = 0; v < V; ++v)
+                        if (ok[v]) *(f4 *)(gp + (v * 64 + lane) * 4) = g[v];
+                    gg.x += group_sum<64>(sg0) * rk0;
+                    og0 += group_sum<64>(so0) * rk0;
+                    if (!SLOW) {
+                        gg.y += group_sum<64>(sg1) * rk1;
+                        og1 += group_sum<64>(so1) * rk1;
+                    }
+                    if (lane == 0) *(f2 *)gap = gg;
+                }
+                if (cur != NONE) write_back();
+                if (lane == 0) lsum += (double)tsum;
+            }
+        }
+    __shared__ double wg_loss[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off);
+    if (lane == 0) wg_loss[threadIdx.x >> 6] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double s = wg_loss[0] + wg_loss[1] + wg_loss[2] + wg_loss[3];
+        if (s != 0.0) atomicAdd(a.loss + (blockIdx.x % LOSS_SLOTS), s);
+    }
+}
+
+// sum over the plan's ratings of (r - p.q)^2 in scaled units, rows of any width (one rating per wavefront)
+__global__ __launch_bounds__(256) void sq_err_entries_wide(const float *own_rows, const float *gat_rows, const EntryD *entries,
+                                                           long long n_entries, int ka, double *out)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    double lsum = 0.0;
+    for (long long i = wave; i < n_entries; i += nwaves) {
+        const EntryD e = entries[i];
+        if (e.gat < 0) continue;
+        const float *const o = own_rows + (size_t)(e.own & 0x3FFFFFFFu) * ka, *const g = gat_rows + (size_t)(e.gat & 0x3FFFFFFF) * ka;
+        float z = 0.0f;
+        for (int d = lane * 4; d < ka; d += 256) {
+            const f4 x = *(const f4 *)(o + d), y = *(const f4 *)(g + d);
+            z += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        }
+        z = group_sum<64>(z);
+        const float err = e.r - z;
+        if (lane == 0) lsum += (double)(err * err);
+    }
+    if (lane == 0 && lsum != 0.0) atomicAdd(out, lsum);
+}
+
 // Fold the copies of the rows that are split over several workgroups into their rows (launched behind every round that
 // holds such a row; one wave per combine slot).  A row with more ratings in a block than one workgroup does in a launch
 // is worked on by n workgroups, each on its own LDS copy that starts from the row p0 of before the launch; every copy adds
@@ -1175,8 +1321,26 @@ static void launch_round_t(const RoundArgs &a, int grid, hipStream_t s)
         hipLaunchKernelGGL((sgd_round<LANES, false, false>), dim3(grid), dim3(256), 0, s, a);
 }
 
+template <int V>
+static void launch_round_wide_t(const RoundArgs &a, int grid, hipStream_t s)
+{
+    if (a.slow_only)
+        hipLaunchKernelGGL((sgd_round_wide<V, true>), dim3(grid), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((sgd_round_wide<V, false>), dim3(grid), dim3(256), 0, s, a);
+}
+
 hipError_t launch_sgd_round(int lanes, const RoundArgs &a, int grid, hipStream_t s)
 {
+    if (a.ka > 256) { // V float4 per lane (plans of such problems hold wave tasks only)
+        if (lanes != 64 || a.ka > 1024) return hipErrorInvalidValue;
+        switch ((a.ka + 255) / 256) {
+        case 2: launch_round_wide_t<2>(a, grid, s); break;
+        case 3: launch_round_wide_t<3>(a, grid, s); break;
+        default: launch_round_wide_t<4>(a, grid, s); break;
+        }
+        return hipGetLastError();
+    }
     switch (lanes) {
     case 2: launch_round_t<2>(a, grid, s); break;
     case 4: launch_round_t<4>(a, grid, s); break;
@@ -1219,6 +1383,10 @@ hipError_t launch_sq_err_entries(int lanes, const float *own_rows, const float *
         hipLaunchKernelGGL(sq_err_entries<L>, dim3(grid), dim3(256), 0, s, own_rows, gat_rows,  \
                            entries, n_entries, ka, out);                                        \
         break;
+    if (ka > 256) {
+        hipLaunchKernelGGL(sq_err_entries_wide, dim3(grid), dim3(256), 0, s, own_rows, gat_rows, entries, n_entries, ka, out);
+        return hipGetLastError();
+    }
     switch (lanes) {
         MFX_CASE(2) MFX_CASE(4) MFX_CASE(8) MFX_CASE(16) MFX_CASE(32) MFX_CASE(64)
     default: return hipErrorInvalidValue;

@@ -23,7 +23,7 @@ namespace mfx {
 int lanes_for(int ka)
 {
     int need = (ka + 3) / 4, l = 2;
-    while (l < need) l <<= 1;
+    while (l < need && l < 64) l <<= 1; // (k_a > 256: a whole wavefront per rating, several float4 per lane)
     return l;
 }
 
@@ -433,6 +433,7 @@ void plan_sizes(long long nnz, int NB, int G, const PlanConfig &cfg, int &target
     // not have (+2 % final RMSE on 2000 x 1500 problems).  There a heavy row simply is one long list of a wave task --
     // every rating sees the one before it -- and the launch takes as long as that list; nobody times tiny problems.
     if (cfg.waves_per_stripe <= 4 && cfg.task_steps <= 0) hot_len = 0x3FFFFFFF; // (an explicit task size keeps the workgroup tasks: tests)
+    if (k_aligned(cfg.k) > 256) hot_len = 0x3FFFFFFF; // rows wider than one float4 per lane: wave tasks only (kernels.hip sgd_round_wide)
 }
 
 void plan_hot_gathered(const PlanConfig &cfg, Plan &p)

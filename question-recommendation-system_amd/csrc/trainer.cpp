@@ -239,7 +239,7 @@ static mfx::PlanConfig plan_config(const mfx_options &opt, int stripes, int wgs_
     cfg.waves_per_stripe = wgs_per_xcd * waves_per_wg;
     cfg.waves_per_wg = waves_per_wg;
     cfg.wgs_hw = wgs_grid;
-    cfg.swap_heavy = opt.no_swap == 0 && knob_int("MFX_NO_SWAP", 0) == 0;
+    cfg.swap_heavy = opt.no_swap == 0 && knob_int("MFX_NO_SWAP", 0) == 0 && mfx::k_aligned(opt.k) <= 256; // (wide rows: one role, kernels.hip sgd_round_wide)
     cfg.threads = g_host_threads;
     return cfg;
 }
@@ -251,8 +251,8 @@ static int check_options(const mfx_options &opt)
     if (opt.lambda_p2 < 0 || opt.lambda_q2 < 0)
         return fail(MFX_E_ARG, "regularization coefficient must be non-negative");
     if (!(opt.eta > 0)) return fail(MFX_E_ARG, "learning rate must be greater than zero");
-    if (mfx::k_aligned(opt.k) > 256)
-        return fail(MFX_E_UNSUPPORTED, "k > 256 is not supported by the gfx950 kernel family yet");
+    if (mfx::k_aligned(opt.k) > 1024)
+        return fail(MFX_E_UNSUPPORTED, "k > 1024 is not supported by the gfx950 kernel family (four float4 per lane at most)");
     return MFX_OK;
 }
 

@@ -31,7 +31,7 @@ def internal(R, t):
     return Ri
 
 
-@pytest.mark.parametrize("k", [8, 16, 32, 40, 64, 128, 200])
+@pytest.mark.parametrize("k", [8, 16, 32, 40, 64, 128, 200, 256, 320, 520, 1000])  # (beyond 256: several float4 per lane, sgd_round_wide)
 @pytest.mark.parametrize("slow", [True, False])
 def test_single_pass_matches_oracle_update(pkg, orc, k, slow):
     """Every rating touches its own user and item: order cannot matter, so the kernel must
@@ -83,6 +83,7 @@ TRAIN_CASES = [  # m, n, nnz, k, iters
     (2000, 1500, 120000, 16, 8), (3000, 2000, 100000, 8, 8), (3000, 2000, 100000, 40, 6),
     (20000, 10000, 2000000, 32, 10), (20000, 10000, 2000000, 64, 6),
     (5000, 4000, 400000, 128, 5), (60000, 30000, 6000000, 32, 8),
+    (5000, 4000, 400000, 320, 5),  # rows wider than one float4 per lane (kernels.hip sgd_round_wide)
 ]
 
 

@@ -240,7 +240,7 @@ def test_plan_edge_cases(pkg, orc):
 
 def test_bad_arguments_fail_loudly(pkg):
     R = np.array([(0, 0, 1.0)], dtype=pkg.NODE)
-    for kw in (dict(k=0), dict(k=8, eta=0.0), dict(k=8, lambda_p2=-1.0), dict(k=300)):
+    for kw in (dict(k=0), dict(k=8, eta=0.0), dict(k=8, lambda_p2=-1.0), dict(k=1100)):  # (k up to 1024: four float4 per lane)
         with pytest.raises(pkg.MfxError):
             pkg.HostPlan(R, 1, 1, **kw)
     with pytest.raises(pkg.MfxError):
