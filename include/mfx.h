@@ -36,7 +36,7 @@ typedef struct mfx_node { int u; int v; float r; } mfx_node;
 typedef struct mfx_trainer mfx_trainer;
 
 typedef struct mfx_options {
-    int k;             /* latent factors (mf_parameter.k, mf/mf.h:54)                  */
+    int k;             /* latent factors (mf_parameter.k, mf/mf.h:54); 1 .. 1024       */
     float lambda_p2;   /* mf/mf.h:59                                                   */
     float lambda_q2;   /* mf/mf.h:61                                                   */
     float eta;         /* mf/mf.h:62                                                   */
@@ -45,7 +45,9 @@ typedef struct mfx_options {
     int wg_per_cu;     /* resident 256-thread workgroups per CU; 0 = auto              */
     int task_steps;    /* ratings per lane-group per task; 0 = auto                    */
     int no_swap;       /* 1: leave the heavy rows of the GATHERED side on the lock-free side.  Default 0: their ratings run in
-                          workgroup tasks with the roles swapped (DESIGN.md "Heavy rows"; tests and A/B runs set it) */
+                          workgroup tasks with the roles swapped (DESIGN.md "Heavy rows"; tests and A/B runs set it -- with it the
+                          popular rows of that side lose most of their accumulator growth, and streams with a heavy head
+                          can overflow at k <= 16: measured on the bench stream, profiles/experiments/r03_k_sweep_100M.log) */
     int rk_mode;       /* 0: 1/8 for both accumulator slots (SSE build as shipped,
                           mf.cpp:1233-1234); 1: 1/(k_a-8) for slot 1 (mf.cpp:1314-1315) */
     int owner_side;    /* 0 auto (side with fewer rows), 1 users (P), 2 items (Q)      */

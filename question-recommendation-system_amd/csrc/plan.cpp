@@ -634,7 +634,8 @@ void finish_plan(std::vector<std::vector<Visit>> &block_visits, const PlanConfig
         for (const TaskDesc &t : p.tasks) lv += (long long)t.nsteps * G;
         for (int b = 0; b < NB; ++b) nv += (long long)block_visits[b].size();
         const double mean_visit = nv > 0 ? (double)p.nnz / (double)nv : 0.0;
-        const double steps = p.tasks.empty() ? 1.0 : (double)lv / (double)G / (double)p.tasks.size();
+        // (steps of a wave in a launch: its tasks one after the other)
+        const double steps = p.tasks.empty() ? 1.0 : (double)lv / (double)G / (double)p.tasks.size() * (double)std::max(1, tasks_per_wave);
         p.merge_back = p.swap_heavy && mean_visit > 0.05 * steps;
     }
     lap("concatenate");
