@@ -48,9 +48,36 @@ __device__ __forceinline__ float dpp(float v)
         float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 
+// x + the value of the lane 16 (32) positions across: the butterfly step that crosses 16-lane rows.  gfx950 has VALU
+// instructions for it (v_permlane16_swap / v_permlane32_swap: with the same value in both operands the two results are "mine" and
+// "the other row's"); ds_bpermute (__shfl_xor) goes through the LDS and costs a round trip per value -- five values per step at
+// k >= 128, fourteen per step of a workgroup task at k = 64.  Bit-identical to the __shfl_xor form
+// (scripts/probes/permlane_probe.hip).  Inline asm: given the builtin with one value for both operands, hipcc 7.2 folds the two
+// results into one.
+__device__ __forceinline__ float xor16_sum(float x)
+{
+#ifdef MFX_SHFL_XOR // experiment/bisect: the LDS form
+    return x + __shfl_xor(x, 16);
+#else
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+#endif
+}
+__device__ __forceinline__ float xor32_sum(float x)
+{
+#ifdef MFX_SHFL_XOR
+    return x + __shfl_xor(x, 32);
+#else
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+#endif
+}
+
 // Sum over the LANES-lane group this lane belongs to; every lane gets the total.
 // quad_perm swaps for 1 and 2, row_half_mirror / row_mirror for 4 and 8 (valid because
-// the halves are already uniform at that point), ds_bpermute beyond a 16-lane row.
+// the halves are already uniform at that point), permlane swaps beyond a 16-lane row.
 template <int LANES>
 __device__ __forceinline__ float group_sum(float x)
 {
@@ -58,8 +85,8 @@ __device__ __forceinline__ float group_sum(float x)
     if (LANES >= 4) x += dpp<0x4E>(x);  // quad_perm [2,3,0,1]
     if (LANES >= 8) x += dpp<0x141>(x); // row_half_mirror
     if (LANES >= 16) x += dpp<0x140>(x); // row_mirror
-    if (LANES >= 32) x += __shfl_xor(x, 16);
-    if (LANES >= 64) x += __shfl_xor(x, 32);
+    if (LANES >= 32) x = xor16_sum(x);
+    if (LANES >= 64) x = xor32_sum(x);
     return x;
 }
 
@@ -71,8 +98,8 @@ __device__ __forceinline__ float cross_group_sum(float x)
     if (LANES <= 2) x += dpp<0x122>(x);  // row_ror:2
     if (LANES <= 4) x += dpp<0x124>(x);  // row_ror:4
     if (LANES <= 8) x += dpp<0x128>(x);  // row_ror:8
-    if (LANES <= 16) x += __shfl_xor(x, 16);
-    if (LANES <= 32) x += __shfl_xor(x, 32);
+    if (LANES <= 16) x = xor16_sum(x);
+    if (LANES <= 32) x = xor32_sum(x);
     return x;
 }
 
