@@ -60,7 +60,7 @@ __device__ __forceinline__ float xor16_sum(float x)
     return x + __shfl_xor(x, 16);
 #else
     float a = x, b = x;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); // (the wait states a freshly written source needs)
     return a + b;
 #endif
 }
@@ -70,7 +70,7 @@ __device__ __forceinline__ float xor32_sum(float x)
     return x + __shfl_xor(x, 32);
 #else
     float a = x, b = x;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return a + b;
 #endif
 }

@@ -7,13 +7,13 @@ typedef unsigned u2v __attribute__((ext_vector_type(2)));
 __device__ inline float xor16_sum(float x)
 {
     float a = x, b = x;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return a + b;
 }
 __device__ inline float xor32_sum(float x)
 {
     float a = x, b = x;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return a + b;
 }
 __global__ void k(const float *in, float *o16, float *o32, float *r16, float *r32)
