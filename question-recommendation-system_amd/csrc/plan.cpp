@@ -220,10 +220,11 @@ static BlockShape block_shape(const std::vector<Visit> &raw, int G, int W, int w
     sh.wide = hw > wgs_cap;
     const long long hsum = hs[0] + hs[1];
     // A step of a workgroup task costs more than a step of a wave task: the lists' changes of the heavy row are summed
-    // across the wave (ds_bpermute beyond a 16-lane row) and added to LDS with atomics.  Measured on configs[1] (k = 32,
-    // launches of a few waves per CU): 1.09 us against 0.56 us; at k = 128 the two are equal.  (A cost model for the
-    // balance of a launch only; no result depends on it.)
-    const long long c10 = G >= 8 ? 20 : G == 4 ? 15 : G == 2 ? 11 : 10; // cost of a workgroup step in tenths of a wave step
+    // across the wave and added to LDS with atomics.  The weights are where the epoch time of configs[1] (k = 32) and
+    // configs[2] (k = 64) is flat in them (profiles/experiments/r03_wide_launches.log, last section: 16 .. 20 and 10 .. 12
+    // tenths); at k = 128 the two kinds of step measured equal.  (A cost model for the balance of a launch only; no result
+    // depends on it.)
+    const long long c10 = knob_int("MFX_WG_COST10", G >= 8 ? 18 : G == 4 ? 11 : 10); // cost of a workgroup step in tenths of a wave step
     // n workgroups for the heavy rows, the others (at most the capped ones) for the ordinary rows: the launch takes
     // max(heavy steps / n, ordinary ratings / lists of the others).  The smallest n that reaches the minimum: fewer copies of
     // a row fold better.
