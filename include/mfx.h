@@ -66,8 +66,8 @@ typedef struct mfx_options {
                           first); a caller who wants round 2's speed on 10 M-rating problems sets 12.                     */
     int wide;          /* 1: a WIDE launch -- where the concurrency cap holds a launch below what the chip runs anyway, the idle
                           workgroups take the heavy rows (the lists of one heavy row and of its copies never meet each other on a
-                          row of the other side).  Twice to four times the speed on skewed 10 M-rating problems (configs[1] 3.7 ->
-                          1.85 ms per epoch at -0.6 % / +0.1 %), but the rows of the other side are updated that much more often per
+                          row of the other side).  Twice to four times the speed on skewed 10 M-rating problems (configs[1] 3.4 ->
+                          1.8 ms per epoch at -0.6 % / -0.1 %), but the rows of the other side are updated that much more often per
                           unit of time and lose accordingly more updates: +6.0 % final RMSE on a Zipf(1.1) law at k = 64 where the
                           default stays at +2.4 %.  Default 0.  (DESIGN.md "Wide launches")                                        */
 } mfx_options;
